@@ -1,0 +1,48 @@
+"""Shared case tables + input regeneration for the golden fixtures (see golden/make_golden.py)."""
+import numpy as np
+
+from weather_model_amd import synth
+
+CONV_CASES = [
+    ("ref_conv1", 3, 1, 2, 6, 16, 2, 1),
+    ("ref_conv2", 3, 16, 3, 6, 32, 3, 1),
+    ("ref_conv3", 3, 32, 3, 6, 32, 3, 1),
+    ("seq_1x2", 2, 8, 1, 6, 16, 1, 2),
+    ("k3x3_c1", 2, 1, 37, 53, 1, 3, 3),
+    ("k3x3_c3to5", 1, 3, 19, 23, 5, 3, 3),
+    ("k3x3_c32", 1, 32, 9, 11, 32, 3, 3),
+    ("k5x5", 1, 2, 13, 17, 3, 5, 5),
+    ("k7x7", 1, 1, 9, 11, 2, 7, 7),
+    ("edge_1x1_out", 2, 2, 3, 3, 4, 3, 3),
+    ("k1x1", 2, 4, 5, 7, 3, 1, 1),
+    ("wide_row", 1, 1, 4, 1440, 1, 3, 3),
+]
+
+REG_CASES = [
+    ("single_f1", 4096, 1, 1, 0, "uniform"),
+    ("multi_p1", 4096, 2, 1, 21, "uniform"),
+    ("f16", 65536, 16, 1, 1, "uniform"),
+    ("f16_normal", 65536, 16, 1, 1, "normal"),
+    ("f64", 32768, 64, 1, 7, "uniform"),
+    ("f5_p3", 5000, 5, 3, 9, "uniform"),
+    ("single_p216", 2048, 432, 216, 13, "normal"),
+]
+
+
+def conv_inputs(ci):
+    name, N, Cin, H, W, Cout, kH, kW = CONV_CASES[ci]
+    bnd = 1.0 / np.sqrt(Cin * kH * kW)
+    x = synth.uniform(1000 + ci, (N, Cin, H, W))
+    w = synth.uniform(2000 + ci, (Cout, Cin, kH, kW), -bnd, bnd)
+    b = synth.uniform(3000 + ci, (Cout,), -bnd, bnd)
+    gy = synth.uniform(4000 + ci, (N, Cout, H - kH + 1, W - kW + 1), -1.0, 1.0)
+    return x, w, b, gy
+
+
+def grid721_inputs(N=2):
+    H, W = 721, 1440
+    x = synth.uniform(2, (N, 1, H, W))
+    w = synth.uniform(3, (1, 1, 3, 3), -1.0 / 3, 1.0 / 3)
+    b = synth.uniform(5, (1,), -1.0 / 3, 1.0 / 3)
+    gy = synth.uniform(4, (N, 1, H - 2, W - 2), -1.0, 1.0)
+    return x, w, b, gy
