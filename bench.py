@@ -1,0 +1,304 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the weather-model hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload all|gram16|conv3x3|gram64]
+
+One JSON line on stdout (rank 0).  Primary workload (`value`) = BASELINE.json configs[1]:
+16-feature least squares on 1e8 synthetic rows per GPU (Gram build + normal-equation solve),
+rows resident in HBM before the timed region.  A "step" = zero the accumulator, one pass of the
+Gram kernel over all rows, (N>1: one RCCL all-reduce of the 18x18 float64 partial Gram), one
+solve.  `also.conv3x3` carries BASELINE configs[2] (3x3 single-channel conv forward +
+backward(weight,bias) over 64 x 721 x 1440 grids) measured in the same run, with its own roofline.
+
+Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL), rows / images sharded
+with no data-path collective; the only exchange is the partial-Gram (or 10-float gradient)
+all-reduce.  Weak scaling: per-GPU work is fixed.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: FP32 matrix 157.3 TFLOP/s
+
+
+def dist_setup(ngpus):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        torch.cuda.set_device(local)
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+    if world != ngpus and rank == 0:
+        print(f"[bench] note: --gpus {ngpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+    return rank, world, local
+
+
+def barrier(world):
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+
+
+def max_over_ranks(value, world):
+    if world == 1:
+        return value
+    import torch.distributed as dist
+    t = torch.tensor([value], device="cuda", dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def timed_steps(step, steps, warmup, world):
+    """W untimed warm-ups, then exactly K steps between barrier+synchronize pairs."""
+    for i in range(warmup):
+        step(i, False)
+    torch.cuda.synchronize()
+    barrier(world)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warmup + i, True)
+    torch.cuda.synchronize()
+    barrier(world)
+    t1 = time.perf_counter()
+    return max_over_ranks(t1 - t0, world)
+
+
+# ------------------------------------------------------------------------------ regression
+def run_gram(F, n_rows, steps, warmup, rank, world, cpu_base):
+    from weather_model_amd import ops, synth
+    import torch.distributed as dist
+    P = 1
+    beta_true = synth.normal(1001, (F, P))
+    # rows of this rank: global row index keeps the data independent of the GPU count
+    row_off = rank * n_rows
+    # generate in slabs to bound the transient footprint
+    X = torch.empty((n_rows, F), device="cuda", dtype=torch.float32)
+    Y = torch.empty((n_rows, P), device="cuda", dtype=torch.float32)
+    slab = 25_000_000
+    bt = torch.from_numpy(beta_true).cuda()
+    from weather_model_amd import _lib
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    for s0 in range(0, n_rows, slab):
+        m = min(slab, n_rows - s0)
+        _lib.check(L.wm_synth_regression_f32(X[s0:].data_ptr(), Y[s0:].data_ptr(), m, F, P, 1,
+                                             row_off + s0, bt.data_ptr(), 0.5, 0.01, 0, st))
+    torch.cuda.synchronize()
+    plan = ops.GramPlan(n_rows, F, P, "cuda")
+
+    evs = []
+
+    def step(i, timed):
+        plan.acc.zero_()
+        if timed:
+            e = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            e[0].record()
+        plan.accumulate(X, Y)
+        if timed:
+            e[1].record()
+            evs.append(e)
+        if world > 1:
+            dist.all_reduce(plan.acc)            # the one exchange step: 18x18 float64
+        plan.solve()
+
+    total = timed_steps(step, steps, warmup, world)
+    kern_ms = [a.elapsed_time(c) for a, c in evs]
+    beta = plan.beta.cpu().numpy()
+    err = float(np.abs(beta[:F] - beta_true).max())
+    rows_total = n_rows * world * steps
+    bytes_per_row = 4 * (F + P)
+    flops_per_row = 2 * F * (F + P)
+    kavg = float(np.mean(kern_ms)) * 1e-3
+    res = {
+        "value": rows_total / total,
+        "ms_per_step": total / steps * 1e3,
+        "planted_coef_max_err": err,
+        "kernel_ms_avg": kavg * 1e3,
+    }
+    if F * 0.5 < MFMA_F32_PEAK_TF * 1e3 / HBM_PEAK_GBS:   # arithmetic intensity F/2 flop/B vs ridge
+        ach = bytes_per_row * n_rows / kavg / 1e9
+        res["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                           "kernel": "gram_f16_kernel" if F == 16 else "gram_tile_kernel",
+                           "algorithmic_bytes_per_row": bytes_per_row}
+    else:
+        ach = flops_per_row * n_rows / kavg / 1e12
+        res["roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF,
+                           "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF, "traffic": None,
+                           "kernel": "gram_tile_kernel",
+                           "algorithmic_flops_per_row": flops_per_row}
+    if cpu_base and rank == 0 and world == 1:
+        from oracle import cpu as ocpu
+        ns = 8_000_000
+        Xs, Ys = X[:ns].cpu().numpy(), Y[:ns].cpu().numpy()
+        best = 1e30
+        t_end = time.perf_counter() + 12.0
+        reps = 0
+        while reps < 2 or (time.perf_counter() < t_end and reps < 20):
+            t0 = time.perf_counter()
+            acc = ocpu.gram(Xs, Ys, f32=True)
+            b = ocpu.normal_solve(acc, F, P)
+            best = min(best, time.perf_counter() - t0)
+            reps += 1
+        res["cpu_baseline"] = {"value": ns / best, "unit": "rows/s", "cores": ocpu.threads(),
+                               "kind": "port",
+                               "sample": f"{ns} of the same rows (F={F}), oracle/wm_oracle.c "
+                                         f"float32 Gram + float64 solve, OpenMP, best of {reps}",
+                               "coef_max_diff_vs_gpu": float(np.abs(b - beta).max())}
+    del X, Y
+    torch.cuda.empty_cache()
+    return res
+
+
+# ------------------------------------------------------------------------------ convolution
+def run_conv(steps, warmup, rank, world, cpu_base, N=64, H=721, W=1440):
+    from weather_model_amd import ops, _lib
+    import torch.distributed as dist
+    L = _lib.lib()
+    nset = 3        # rotate buffer sets so the 256 MiB Infinity Cache cannot serve the reads
+    w = ops.synth_uniform((1, 1, 3, 3), seed=3, lo=-1 / 3, hi=1 / 3)
+    b = ops.synth_uniform((1,), seed=5, lo=-1 / 3, hi=1 / 3)
+    xs = [ops.synth_uniform((N, 1, H, W), seed=2, offset=(rank * nset + k) * N * H * W)
+          for k in range(nset)]
+    gys = [ops.synth_uniform((N, 1, H - 2, W - 2), seed=4, lo=-1.0, hi=1.0,
+                             offset=(rank * nset + k) * N * H * W) for k in range(nset)]
+    ys = [torch.empty((N, 1, H - 2, W - 2), device="cuda") for _ in range(nset)]
+    nbytes = L.wm_conv2d_bwd_wb_workspace_bytes(N, 1, H, W, 1, 3, 3)
+    ws = torch.empty((nbytes,), device="cuda", dtype=torch.uint8)
+    grads = torch.zeros((10,), device="cuda")
+    fwd_ev, bwd_ev = [], []
+
+    def step(i, ev):
+        k = i % nset
+        st = torch.cuda.current_stream().cuda_stream
+        if ev:
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            e[0].record()
+        _lib.check(L.wm_conv2d_fwd_f32(xs[k].data_ptr(), w.data_ptr(), b.data_ptr(),
+                                       ys[k].data_ptr(), N, 1, H, W, 1, 3, 3, 0, st))
+        if ev:
+            e[1].record()
+        _lib.check(L.wm_conv2d_bwd_wb_f32(xs[k].data_ptr(), gys[k].data_ptr(), grads.data_ptr(),
+                                          grads[9:].data_ptr(), ws.data_ptr(), ws.numel(),
+                                          N, 1, H, W, 1, 3, 3, st))
+        if ev:
+            e[2].record()
+            fwd_ev.append((e[0], e[1]))
+            bwd_ev.append((e[1], e[2]))
+        if world > 1:
+            dist.all_reduce(grads)               # DP weight-gradient exchange (10 floats)
+
+    total = timed_steps(step, steps, warmup, world)
+    pts = N * H * W
+    fwd_ms = float(np.mean([a.elapsed_time(c) for a, c in fwd_ev]))
+    bwd_ms = float(np.mean([a.elapsed_time(c) for a, c in bwd_ev]))
+    out_pts = N * (H - 2) * (W - 2)
+    fwd_bytes = 4 * (pts + out_pts)
+    bwd_bytes = 4 * (pts + out_pts)
+    res = {
+        "value": pts * world * steps / total, "unit": "grid-pts/s", "ms_per_step": total / steps * 1e3,
+        "config": {"workload": "conv 3x3 C=1 fwd+bwd(weight,bias), 721x1440 grid, batch 64 per GPU"},
+        "fwd_ms": fwd_ms, "bwd_wb_ms": bwd_ms,
+        "roofline": {"bound": "hbm",
+                     "achieved": (fwd_bytes + bwd_bytes) / ((fwd_ms + bwd_ms) * 1e-3) / 1e9,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
+                     "kernel": "conv_fwd_c1_kernel<3,3> + conv_bwd_wb_c1_kernel<3,3>",
+                     "fwd_GBs": fwd_bytes / (fwd_ms * 1e-3) / 1e9,
+                     "bwd_wb_GBs": bwd_bytes / (bwd_ms * 1e-3) / 1e9,
+                     "algorithmic_bytes_per_point": 16},
+    }
+    res["roofline"]["frac"] = res["roofline"]["achieved"] / HBM_PEAK_GBS
+    if cpu_base and rank == 0 and world == 1:
+        from oracle import cpu as ocpu
+        Nc = 8
+        xh = xs[0][:Nc].cpu().numpy()
+        gyh = gys[0][:Nc].cpu().numpy()
+        wh, bh = w.cpu().numpy(), b.cpu().numpy()
+        best = 1e30
+        t_end = time.perf_counter() + 10.0
+        reps = 0
+        while reps < 2 or (time.perf_counter() < t_end and reps < 50):
+            t0 = time.perf_counter()
+            ocpu.conv2d_fwd_bwd_wb_f32(xh, wh, bh, gyh)
+            best = min(best, time.perf_counter() - t0)
+            reps += 1
+        res["cpu_baseline"] = {"value": Nc * H * W / best, "unit": "grid-pts/s",
+                               "cores": ocpu.threads(), "kind": "port",
+                               "sample": f"{Nc} of the 64 images, oracle/wm_oracle.c float32 forward "
+                                         f"+ float64 backward(weight,bias), OpenMP, best of {reps}"}
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="all", choices=["all", "gram16", "conv3x3", "gram64"])
+    ap.add_argument("--rows", type=int, default=100_000_000, help="rows per GPU (gram workloads)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (weather_model_amd has no CPU fallback)")
+    rank, world, _ = dist_setup(args.gpus)
+    cpu_base = not args.no_cpu_baseline
+
+    out = {
+        "metric": "regression rows/s (16-feature least squares, Gram build + solve)",
+        "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+    }
+    if args.workload in ("all", "gram16", "gram64"):
+        F = 64 if args.workload == "gram64" else 16
+        rows = args.rows if F == 16 else min(args.rows, 25_000_000)
+        r = run_gram(F, rows, args.steps, args.warmup, rank, world, cpu_base)
+        out.update({"value": r["value"], "ms_per_step": r["ms_per_step"],
+                    "roofline": r["roofline"],
+                    "config": {"workload": f"multipleRegression least squares: F={F}, P=1, "
+                                           f"{rows} rows per GPU, X~U(0,1), Gram (fp32 MFMA, fp64 "
+                                           f"combine) + normal-equation solve",
+                               "rows_per_gpu": rows, "features": F,
+                               "parallelism": f"dp{world} (row shards, one 18x18 f64 all-reduce)"},
+                    "planted_coef_max_err": r["planted_coef_max_err"],
+                    "kernel_ms_avg": r["kernel_ms_avg"]})
+        if "cpu_baseline" in r:
+            out["cpu_baseline"] = r["cpu_baseline"]
+    if args.workload in ("all", "conv3x3"):
+        c = run_conv(args.steps, args.warmup, rank, world, cpu_base)
+        if args.workload == "conv3x3":
+            out.update({"metric": "grid-pts/s conv fwd+bwd", "unit": "grid-pts/s",
+                        "value": c["value"], "ms_per_step": c["ms_per_step"],
+                        "roofline": c["roofline"], "config": c["config"]})
+            if "cpu_baseline" in c:
+                out["cpu_baseline"] = c["cpu_baseline"]
+        else:
+            out["also"] = {"conv3x3": c}
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,118 @@
+/*
+ * wm.h -- C ABI of libwm.so, the MI355X (gfx950) implementation of the weather-model hot path.
+ *
+ * The reference (akollgaa/weather-model) has no FFI of its own: its hot path is reached through
+ * two LIBRARY OPERATORS called from Python --
+ *     torch.nn.Conv2d / torch.nn.functional.conv2d   newConvolution.py:129-133,149-158 (+ :184)
+ *     keras.layers.Dense(activation='linear') + MSE  multipleRegression.py:273-298,
+ *                                                    singleRegression.py:74-96
+ * -- so the drop-in boundary is the operator level.  Every entry point below cites the reference
+ * call it replaces.  The reference-side binding is a ctypes stub.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory unless a comment says host.
+ *   - every call is asynchronous on the hipStream_t passed as `stream` (NULL = default stream);
+ *     nothing synchronises, nothing allocates, nothing is freed.  The caller owns all buffers,
+ *     including the workspaces sized by the *_workspace_bytes() queries.
+ *   - return 0 on success, a negative WM_ERR_* code otherwise; wm_last_error() returns a
+ *     thread-local message for the last failure on the calling thread.
+ *   - tensors are contiguous float32 NCHW; conv weights are (Cout,Cin,kH,kW) (PyTorch order, so a
+ *     reference state_dict is usable as is).  Convolutions are cross-correlations with valid
+ *     padding, stride 1, dilation 1, groups 1 -- the only convention the reference uses.
+ */
+#ifndef WM_H
+#define WM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WM_OK               0
+#define WM_ERR_INVALID     -1   /* bad argument (null pointer, non-positive size, shape mismatch) */
+#define WM_ERR_UNSUPPORTED -2   /* shape outside what the kernels implement */
+#define WM_ERR_WORKSPACE   -3   /* workspace missing or too small */
+#define WM_ERR_HIP         -4   /* a HIP runtime call or kernel launch failed */
+#define WM_ERR_NO_DEVICE   -5   /* no gfx950 device visible */
+
+/* library version (major*10000 + minor*100 + patch) and last error text of this thread */
+int         wm_version(void);
+const char *wm_last_error(void);
+/* Number of compute units of the current device (negative WM_ERR_* on failure). */
+int         wm_device_cus(void);
+
+/* ------------------------------------------------------------------ convolution --------- */
+
+/* Replaces torch.nn.functional.conv2d(x, w, b) as called by nn.Conv2d.forward at
+ * newConvolution.py:149,152,155,158 (layers defined :129-133) and the operator convention of
+ * keras Conv3D(..., strides=1, padding='valid', data_format='channels_first') at
+ * convolution.py:164,166.  y[n,o,i,j] = b[o] + sum_{c,kh,kw} w[o,c,kh,kw] x[n,c,i+kh,j+kw].
+ * b may be NULL.  relu != 0 fuses the nn.ReLU the reference applies after every conv
+ * (newConvolution.py:150,153,156,159).  y is (N,Cout,H-kH+1,W-kW+1). */
+int wm_conv2d_fwd_f32(const float *x, const float *w, const float *b, float *y,
+                      int N, int Cin, int H, int W, int Cout, int kH, int kW,
+                      int relu, void *stream);
+
+/* Replaces the grad_input leg of autograd for that conv (reached from loss.backward(),
+ * newConvolution.py:184): gx[n,c,p,q] = sum_{o,kh,kw} w[o,c,kh,kw] gy[n,o,p-kh,q-kw]. */
+int wm_conv2d_bwd_data_f32(const float *gy, const float *w, float *gx,
+                           int N, int Cin, int H, int W, int Cout, int kH, int kW,
+                           void *stream);
+
+/* Replaces the grad_weight and grad_bias legs (newConvolution.py:184):
+ *   gw[o,c,kh,kw] = sum_{n,i,j} gy[n,o,i,j] x[n,c,i+kh,j+kw],  gb[o] = sum_{n,i,j} gy[n,o,i,j].
+ * gb may be NULL.  Partial sums go through `workspace` (float64) and are combined in a fixed
+ * order, so results are bitwise reproducible run to run on one device. */
+size_t wm_conv2d_bwd_wb_workspace_bytes(int N, int Cin, int H, int W, int Cout, int kH, int kW);
+int wm_conv2d_bwd_wb_f32(const float *x, const float *gy, float *gw, float *gb,
+                         void *workspace, size_t workspace_bytes,
+                         int N, int Cin, int H, int W, int Cout, int kH, int kW,
+                         void *stream);
+
+/* ------------------------------------------------------------------ least squares ------- */
+
+/* Sufficient statistics of the least-squares problem that the reference's linear Dense stacks
+ * minimise by Adam/MSE (multipleRegression.py:273-298, rows built at :217-234;
+ * singleRegression.py:74-96).  With Z = [X | 1 | Y] (D = F+1+P columns),
+ *   acc[a*D + b] += sum_{r<n} Z[r][a] * Z[r][b]            (float64, row-major D x D)
+ * X is n x F row-major float32, Y is n x P row-major float32.  acc is a RUNNING sum: zero it
+ * before the first call; several calls (row chunks, or one per GPU followed by an all-reduce)
+ * accumulate.  Products are formed in float32 (MFMA), summed in float32 over at most 1024 rows
+ * per accumulator and combined in float64 in a fixed order (bitwise reproducible). */
+size_t wm_gram_workspace_bytes(int64_t n, int F, int P);
+int wm_gram_f32(const float *X, const float *Y, int64_t n, int F, int P, double *acc,
+                void *workspace, size_t workspace_bytes, void *stream);
+
+/* Solves the normal equations held in acc for the affine map the reference's model spans:
+ *   beta is (F+1) x P row-major float64, row F is the intercept (0 if fit_intercept == 0).
+ * ridge is added to the diagonal of the (centred) X'X.  *status (device int, may be NULL) is set
+ * to 0, or to 1 if the system was not positive definite (beta is then left NaN). */
+size_t wm_normal_solve_workspace_bytes(int F, int P);
+int wm_normal_solve_f64(const double *acc, int F, int P, int fit_intercept, double ridge,
+                        double *beta, int *status,
+                        void *workspace, size_t workspace_bytes, void *stream);
+
+/* y[r][p] = sum_f X[r][f] beta[f][p] + beta[F][p]  -- replaces model.predict([x1, x2])
+ * (multipleRegression.py:451, singleRegression.py:579) for the fitted linear map. */
+int wm_linear_predict_f32(const float *X, const double *beta, float *Yhat,
+                          int64_t n, int F, int P, void *stream);
+
+/* ------------------------------------------------------------------ synthetic data ------ */
+
+/* Counter-based generator: element i of `out` depends only on (seed, offset + i).  Same hash as
+ * weather_model_amd/synth.py.  No reference counterpart (the reference reads WRF files). */
+int wm_synth_uniform_f32(float *out, int64_t count, uint64_t seed, uint64_t offset,
+                         float lo, float hi, void *stream);
+/* Rows [row_offset, row_offset+n) of the synthetic regression problem of SURVEY.md 8d:
+ * X ~ U(0,1) (dist 0) or N(0,1) (dist 1); Y = X beta + intercept + N(0, noise^2).
+ * beta: device, F x P float32. */
+int wm_synth_regression_f32(float *X, float *Y, int64_t n, int F, int P, uint64_t seed,
+                            uint64_t row_offset, const float *beta, float intercept,
+                            float noise, int dist, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WM_H */

@@ -1,0 +1,135 @@
+"""GPU parity: HIP conv2d (through the C ABI) vs the float64 oracle and the golden fixtures.
+Tolerance (BASELINE.json north_star): 1e-5 relative, ||a-b||_inf / ||b||_inf, float32."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import relinf
+from cases import CONV_CASES, conv_inputs, grid721_inputs
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("ci", range(len(CONV_CASES)), ids=[c[0] for c in CONV_CASES])
+def test_conv_matches_oracle_and_golden(ci, conv_golden):
+    from weather_model_amd import ops
+    from oracle import cpu as ocpu
+    name = CONV_CASES[ci][0]
+    x, w, b, gy = conv_inputs(ci)
+    y = ops.conv2d_forward(_dev(x), _dev(w), _dev(b)).cpu().numpy()
+    assert relinf(y, ocpu.conv2d_fwd(x, w, b)) < TOL
+    assert relinf(y, conv_golden[f"{name}/y_f64"]) < TOL
+    gx = ops.conv2d_backward_data(_dev(gy), _dev(w), x.shape).cpu().numpy()
+    assert relinf(gx, conv_golden[f"{name}/gx_f64"]) < TOL
+    gw, gb = ops.conv2d_backward_wb(_dev(x), _dev(gy), w.shape)
+    assert relinf(gw.cpu().numpy(), conv_golden[f"{name}/gw_f64"]) < TOL
+    assert relinf(gb.cpu().numpy(), conv_golden[f"{name}/gb_f64"]) < TOL
+    # no-bias and fused-ReLU variants
+    y0 = ops.conv2d_forward(_dev(x), _dev(w), None).cpu().numpy()
+    assert relinf(y0, ocpu.conv2d_fwd(x, w, None)) < TOL
+    yr = ops.conv2d_forward(_dev(x), _dev(w), _dev(b), relu=True).cpu().numpy()
+    assert relinf(yr, np.maximum(ocpu.conv2d_fwd(x, w, b), 0.0)) < TOL
+
+
+def test_conv_full_grid_721x1440(conv_golden):
+    """BASELINE config 3 grid (2 images): checksums and corner tiles of the golden fixture."""
+    from weather_model_amd import ops
+    g = conv_golden
+    x, w, b, gy = grid721_inputs()
+    y = ops.conv2d_forward(_dev(x), _dev(w), _dev(b)).cpu().numpy().astype(np.float64)
+    assert abs(y.sum() - g["grid721/y_sum"]) < 1e-6 * abs(g["grid721/y_sum"])
+    assert abs((y ** 2).sum() - g["grid721/y_sumsq"]) < 1e-6 * g["grid721/y_sumsq"]
+    assert relinf(y[:, :, :8, :8], g["grid721/y_tl"]) < TOL
+    assert relinf(y[:, :, -8:, -8:], g["grid721/y_br"]) < TOL
+    assert relinf(y[:, :, :8, -8:], g["grid721/y_tr"]) < TOL
+    assert relinf(y[:, :, 355:363, 715:723], g["grid721/y_mid"]) < TOL
+    gw, gb = ops.conv2d_backward_wb(_dev(x), _dev(gy), w.shape)
+    assert relinf(gw.cpu().numpy(), g["grid721/gw"]) < TOL
+    assert relinf(gb.cpu().numpy(), g["grid721/gb"]) < TOL
+    gx = ops.conv2d_backward_data(_dev(gy), _dev(w), x.shape).cpu().numpy().astype(np.float64)
+    assert abs((gx ** 2).sum() - g["grid721/gx_sumsq"]) < 1e-6 * g["grid721/gx_sumsq"]
+    assert relinf(gx[:, :, :8, :8], g["grid721/gx_tl"]) < TOL
+    assert relinf(gx[:, :, -8:, -8:], g["grid721/gx_br"]) < TOL
+
+
+@pytest.mark.parametrize("shape", [
+    (1, 1, 3, 19, 1, 3, 3),       # a single output row, OW = 17 (stencil path, ragged strip)
+    (5, 1, 40, 66, 1, 3, 3),      # ranges that cross image boundaries
+    (3, 1, 33, 130, 1, 5, 5),
+    (2, 1, 9, 70, 1, 3, 1), (2, 1, 9, 70, 1, 1, 3), (2, 1, 9, 70, 1, 2, 2),
+    (2, 1, 9, 70, 1, 1, 1), (4, 1, 2, 64, 1, 2, 1), (4, 1, 6, 65, 1, 1, 2),
+    (1, 1, 7, 7, 1, 7, 7),        # generic path, 1x1 output
+    (2, 3, 8, 9, 2, 2, 3),        # generic path, odd everything
+])
+def test_conv_ragged_shapes_vs_oracle(shape):
+    from weather_model_amd import ops, synth
+    from oracle import cpu as ocpu
+    N, Cin, H, W, Cout, kH, kW = shape
+    x = synth.uniform(50, (N, Cin, H, W), -1, 1)
+    w = synth.uniform(51, (Cout, Cin, kH, kW), -1, 1)
+    b = synth.uniform(52, (Cout,), -1, 1)
+    gy = synth.uniform(53, (N, Cout, H - kH + 1, W - kW + 1), -1, 1)
+    y = ops.conv2d_forward(_dev(x), _dev(w), _dev(b)).cpu().numpy()
+    assert relinf(y, ocpu.conv2d_fwd(x, w, b)) < TOL
+    gw, gb = ops.conv2d_backward_wb(_dev(x), _dev(gy), w.shape)
+    ogw, ogb = ocpu.conv2d_bwd_wb(x, gy, w.shape)
+    # weight-gradient sums of +-1 data cancel; scale by the sum of magnitudes bound instead
+    scale = max(np.abs(ogw).max(), 1e-3 * np.sqrt(gy.size))
+    assert np.abs(gw.cpu().numpy() - ogw).max() / scale < TOL
+    assert np.abs(gb.cpu().numpy() - ogb).max() / max(np.abs(ogb).max(), 1e-3 * np.sqrt(gy.size)) < TOL
+    gx = ops.conv2d_backward_data(_dev(gy), _dev(w), x.shape).cpu().numpy()
+    assert relinf(gx, ocpu.conv2d_bwd_data(gy, w, x.shape)) < TOL
+
+
+def test_conv_autograd_matches_torch_semantics():
+    """loss.backward() through Conv2dFunction (the reference call site newConvolution.py:184)."""
+    from weather_model_amd import ops, synth
+    from oracle import cpu as ocpu
+    x = synth.uniform(60, (2, 1, 21, 40))
+    w = synth.uniform(61, (1, 1, 3, 3), -0.3, 0.3)
+    b = synth.uniform(62, (1,), -0.3, 0.3)
+    xt = _dev(x).requires_grad_(True)
+    wt = _dev(w).requires_grad_(True)
+    bt = _dev(b).requires_grad_(True)
+    y = ops.conv2d(xt, wt, bt)
+    loss = (y * y).mean()
+    loss.backward()
+    yo = ocpu.conv2d_fwd(x, w, b)
+    gy = (2.0 * yo / yo.size).astype(np.float32)
+    ogw, ogb = ocpu.conv2d_bwd_wb(x, gy, w.shape)
+    assert relinf(wt.grad.cpu().numpy(), ogw) < 2e-5
+    assert relinf(bt.grad.cpu().numpy(), ogb) < 2e-5
+    assert relinf(xt.grad.cpu().numpy(), ocpu.conv2d_bwd_data(gy, w, x.shape)) < 2e-5
+    # unbatched (C,H,W) input, as the reference passes it (newConvolution.py:149)
+    y3 = ops.conv2d(_dev(x)[0], _dev(w), _dev(b))
+    assert y3.shape == (1, 19, 38)
+    assert torch.equal(y3, y[0].detach())
+
+
+def test_conv_bwd_wb_is_bitwise_reproducible():
+    from weather_model_amd import ops, synth
+    x = _dev(synth.uniform(70, (4, 1, 200, 300)))
+    gy = _dev(synth.uniform(71, (4, 1, 198, 298), -1, 1))
+    a = ops.conv2d_backward_wb(x, gy, (1, 1, 3, 3))
+    b = ops.conv2d_backward_wb(x, gy, (1, 1, 3, 3))
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+def test_conv_error_behaviour():
+    from weather_model_amd import ops, _lib
+    x = torch.zeros(1, 2, 5, 5, device="cuda")
+    with pytest.raises(RuntimeError, match="channels"):
+        ops.conv2d(x, torch.zeros(1, 3, 3, 3, device="cuda"))
+    with pytest.raises(RuntimeError, match="greater than input"):
+        ops.conv2d(x, torch.zeros(1, 2, 7, 7, device="cuda"))
+    with pytest.raises(NotImplementedError):
+        ops.conv2d(x, torch.zeros(1, 2, 3, 3, device="cuda"), padding=1)
+    L = _lib.lib()
+    rc = L.wm_conv2d_bwd_wb_f32(x.data_ptr(), x.data_ptr(), x.data_ptr(), 0, 0, 0,
+                                1, 2, 5, 5, 1, 3, 3, 0)
+    assert rc == -3 and b"workspace" in L.wm_last_error()

@@ -1,0 +1,140 @@
+"""GPU parity: HIP Gram build + normal-equation solve (through the C ABI) vs the float64 oracle.
+Tolerance (BASELINE.json north_star): regression coefficients 1e-4, max|b-b_ref| / max|b_ref|,
+b_ref = numpy.linalg.lstsq in float64 on the same float32 data (parity unpinned: see
+oracle/wm_oracle.c -- tensorflow/keras, where the reference's fit lives, are absent)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import relinf
+from cases import REG_CASES
+
+pytestmark = pytest.mark.gpu
+COEF_TOL = 1e-4
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("case", REG_CASES, ids=[c[0] for c in REG_CASES])
+def test_gram_and_solve_match_oracle(case, regression_golden):
+    from weather_model_amd import ops, synth
+    from oracle import cpu as ocpu
+    name, n, F, P, seed, dist = case
+    X, Y, _ = synth.regression_problem(n, F, P, seed=seed, dist=dist)
+    acc = ops.gram(_dev(X), _dev(Y))
+    ref = ocpu.gram(X, Y)
+    a = acc.cpu().numpy()
+    assert a[F, F] == n
+    assert np.array_equal(a, a.T)
+    assert relinf(a, ref) < 2e-6          # float32 products, float64 combination
+    beta = ops.normal_solve(acc, F, P).cpu().numpy()
+    assert relinf(beta, regression_golden[f"{name}/beta_lstsq"]) < COEF_TOL
+    assert relinf(beta, ocpu.normal_solve(ref, F, P)) < COEF_TOL
+    # the solve kernel alone, fed the oracle's Gram, agrees to float64 accuracy
+    b2 = ops.normal_solve(_dev(ref), F, P).cpu().numpy()
+    assert relinf(b2, ocpu.normal_solve(ref, F, P)) < 1e-9
+
+
+@pytest.mark.parametrize("n", [1, 3, 15, 16, 17, 63, 1000, 16 * 8 * 3 + 5, 70001])
+def test_gram_f16_ragged_row_counts(n):
+    from weather_model_amd import ops, synth
+    from oracle import cpu as ocpu
+    X, Y, _ = synth.regression_problem(n, 16, 1, seed=33)
+    a = ops.gram(_dev(X), _dev(Y)).cpu().numpy()
+    assert relinf(a, ocpu.gram(X, Y)) < 2e-6
+    assert a[16, 16] == n
+
+
+def test_gram_f16_asymmetric_operands_catch_layout_swaps():
+    """Distinct integer features: exact in float32, so the Gram must be bit-exact; a swapped
+    MFMA operand/result map would transpose or permute entries."""
+    from weather_model_amd import ops
+    from oracle import cpu as ocpu
+    n = 257
+    r = np.arange(n, dtype=np.float32)[:, None]
+    f = np.arange(16, dtype=np.float32)[None, :]
+    X = ((r * 7 + f * f * 3 + f) % 13) + f          # asymmetric in (row, feature)
+    Y = ((r * 5) % 11) - 3.0
+    a = ops.gram(_dev(X), _dev(Y)).cpu().numpy()
+    assert np.array_equal(a, ocpu.gram(X, Y))
+
+
+def test_gram_is_a_running_sum_and_reproducible():
+    from weather_model_amd import ops, synth
+    X, Y, _ = synth.regression_problem(50000, 16, 1, seed=5)
+    Xd, Yd = _dev(X), _dev(Y)
+    whole = ops.gram(Xd, Yd)
+    acc = ops.gram(Xd[:20000], Yd[:20000])
+    acc = ops.gram(Xd[20000:], Yd[20000:], acc)
+    assert relinf(acc.cpu().numpy(), whole.cpu().numpy()) < 1e-9
+    assert torch.equal(ops.gram(Xd, Yd), whole)           # bitwise reproducible
+    # rows may arrive in any order: the sufficient statistic is permutation invariant
+    perm = torch.randperm(50000, device="cuda")
+    assert relinf(ops.gram(Xd[perm], Yd[perm]).cpu().numpy(), whole.cpu().numpy()) < 1e-6
+
+
+def test_gram_unaligned_and_generic_path_agree():
+    from weather_model_amd import ops, synth
+    X, Y, _ = synth.regression_problem(4099, 16, 1, seed=8)
+    Xd, Yd = _dev(X), _dev(Y)
+    fast = ops.gram(Xd, Yd)
+    # a float32 view shifted by one element is 4-byte aligned only -> generic tile kernel
+    buf = torch.empty(X.size + 1, device="cuda", dtype=torch.float32)
+    buf[1:] = Xd.reshape(-1)
+    slow = ops.gram(buf[1:].view(4099, 16), Yd)
+    assert relinf(slow.cpu().numpy(), fast.cpu().numpy()) < 1e-6
+
+
+def test_solve_options_and_singular_systems():
+    from weather_model_amd import ops, synth
+    from oracle import cpu as ocpu
+    X, Y, _ = synth.regression_problem(3000, 5, 2, seed=3)
+    acc = ops.gram(_dev(X), _dev(Y))
+    ref = ocpu.gram(X, Y)
+    for fi in (True, False):
+        for ridge in (0.0, 0.5):
+            b = ops.normal_solve(acc, 5, 2, fit_intercept=fi, ridge=ridge).cpu().numpy()
+            assert relinf(b, ocpu.normal_solve(ref, 5, 2, fi, ridge)) < COEF_TOL
+    Xc = X.copy()
+    Xc[:, 4] = Xc[:, 3]                        # collinear -> not positive definite
+    accc = ops.gram(_dev(Xc), _dev(Y))
+    with pytest.raises(RuntimeError, match="positive definite"):
+        ops.normal_solve(accc, 5, 2)
+    assert np.isnan(ops.normal_solve(accc, 5, 2, check=False).cpu().numpy()).all()
+    assert np.isfinite(ops.normal_solve(accc, 5, 2, ridge=1e-3).cpu().numpy()).all()
+    # empty input is legal and leaves acc untouched
+    z = ops.gram(torch.zeros(0, 5, device="cuda"), torch.zeros(0, 2, device="cuda"))
+    assert float(z.abs().sum()) == 0.0
+
+
+def test_device_generator_matches_host_generator():
+    from weather_model_amd import ops, synth
+    u = ops.synth_uniform((1000, 16), seed=9, lo=-1.0, hi=3.0, offset=77).cpu().numpy()
+    assert np.array_equal(u, synth.uniform(9, (1000, 16), -1.0, 3.0, offset=77))
+    beta = synth.normal(1001, (16, 1))
+    Xd, Yd = ops.synth_regression(5000, 16, 1, seed=1, beta=torch.from_numpy(beta))
+    Xh, Yh, _ = synth.regression_problem(5000, 16, 1, seed=1)
+    assert np.array_equal(Xd.cpu().numpy(), Xh)
+    assert np.abs(Yd.cpu().numpy() - Yh).max() < 1e-4       # Box-Muller: float32 vs float64 libm
+
+
+def test_full_size_property_recovers_planted_coefficients():
+    """Size-independent property at a large row count (2e7 rows generated on the device):
+    the fit recovers the planted beta within the statistical error of the noise, and the
+    Gram of a row-doubled input is exactly twice the Gram (linearity)."""
+    from weather_model_amd import ops, synth
+    n = 20_000_000
+    beta_true = synth.normal(1001, (16, 1))
+    X, Y = ops.synth_regression(n, 16, 1, seed=1, beta=torch.from_numpy(beta_true))
+    acc = ops.gram(X, Y)
+    b = ops.normal_solve(acc, 16, 1).cpu().numpy()
+    assert np.abs(b[:16] - beta_true).max() < 1e-4
+    assert abs(b[16, 0] - 0.5) < 1e-4
+    acc2 = ops.gram(X, Y, acc.clone())
+    assert relinf(acc2.cpu().numpy(), 2.0 * acc.cpu().numpy()) < 1e-12
+    # agreement with the float64 oracle on a slice of the same device data
+    from oracle import cpu as ocpu
+    Xs, Ys = X[:200000].cpu().numpy(), Y[:200000].cpu().numpy()
+    assert relinf(ops.gram(X[:200000], Y[:200000]).cpu().numpy(), ocpu.gram(Xs, Ys)) < 2e-6

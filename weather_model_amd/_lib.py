@@ -1,0 +1,62 @@
+"""ctypes binding of libwm.so (include/wm.h).  Loading fails loudly: there is no CPU fallback."""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libwm.so")
+
+c_int, c_i64, c_u64 = ctypes.c_int, ctypes.c_int64, ctypes.c_uint64
+c_f32, c_f64, c_sz, vp = ctypes.c_float, ctypes.c_double, ctypes.c_size_t, ctypes.c_void_p
+
+# name -> (restype, argtypes); mirrors include/wm.h one to one (tests check the two agree)
+SIGNATURES = {
+    "wm_version": (c_int, []),
+    "wm_last_error": (ctypes.c_char_p, []),
+    "wm_device_cus": (c_int, []),
+    "wm_conv2d_fwd_f32": (c_int, [vp, vp, vp, vp] + [c_int] * 7 + [c_int, vp]),
+    "wm_conv2d_bwd_data_f32": (c_int, [vp, vp, vp] + [c_int] * 7 + [vp]),
+    "wm_conv2d_bwd_wb_workspace_bytes": (c_sz, [c_int] * 7),
+    "wm_conv2d_bwd_wb_f32": (c_int, [vp, vp, vp, vp, vp, c_sz] + [c_int] * 7 + [vp]),
+    "wm_gram_workspace_bytes": (c_sz, [c_i64, c_int, c_int]),
+    "wm_gram_f32": (c_int, [vp, vp, c_i64, c_int, c_int, vp, vp, c_sz, vp]),
+    "wm_normal_solve_workspace_bytes": (c_sz, [c_int, c_int]),
+    "wm_normal_solve_f64": (c_int, [vp, c_int, c_int, c_int, c_f64, vp, vp, vp, c_sz, vp]),
+    "wm_linear_predict_f32": (c_int, [vp, vp, vp, c_i64, c_int, c_int, vp]),
+    "wm_synth_uniform_f32": (c_int, [vp, c_i64, c_u64, c_u64, c_f32, c_f32, vp]),
+    "wm_synth_regression_f32": (c_int, [vp, vp, c_i64, c_int, c_int, c_u64, c_u64, vp, c_f32,
+                                        c_f32, c_int, vp]),
+}
+
+_lib = None
+
+
+class WmError(RuntimeError):
+    """A libwm.so entry point returned a negative WM_ERR_* code."""
+
+    def __init__(self, code, msg):
+        super().__init__(f"libwm error {code}: {msg}")
+        self.code = code
+
+
+def lib() -> ctypes.CDLL:
+    """Load libwm.so (built in-tree by weather_model_amd/build.py).  Raises if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  weather_model_amd has no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)     # AttributeError if the library does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise WmError(rc, lib().wm_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,67 @@
+// common.h -- shared host/device helpers for libwm.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "wm.h"
+
+#define WM_VERSION_NUM 100   // 0.1.0
+
+// ---- thread-local last-error text -------------------------------------------------------
+void wm_set_error(const char *fmt, ...);
+
+#define WM_REQUIRE(cond, code, ...)                  \
+    do {                                             \
+        if (!(cond)) {                               \
+            wm_set_error(__VA_ARGS__);               \
+            return (code);                           \
+        }                                            \
+    } while (0)
+
+#define WM_HIP(call)                                                                   \
+    do {                                                                               \
+        hipError_t e_ = (call);                                                        \
+        if (e_ != hipSuccess) {                                                        \
+            wm_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),        \
+                         __FILE__, __LINE__);                                          \
+            return WM_ERR_HIP;                                                         \
+        }                                                                              \
+    } while (0)
+
+#define WM_LAUNCH_CHECK(name)                                                          \
+    do {                                                                               \
+        hipError_t e_ = hipGetLastError();                                             \
+        if (e_ != hipSuccess) {                                                        \
+            wm_set_error("launch of %s failed: %s", name, hipGetErrorString(e_));      \
+            return WM_ERR_HIP;                                                         \
+        }                                                                              \
+    } while (0)
+
+// Compute units of the current device (cached per device); <= 0 on failure.
+int wm_num_cus();
+
+static inline size_t wm_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- device helpers ---------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+// 4-byte-aligned vector views: rows of a (H-kH+1)-wide tensor start at any dword, the hardware
+// takes dword-aligned dwordx2/x4 accesses, and hipcc emits them for these types.
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}

@@ -1,0 +1,571 @@
+// conv2d.hip -- valid / stride-1 cross-correlation forward, backward-data and backward-weight+bias.
+//
+// Replaces torch.nn.functional.conv2d and its autograd triple as the reference reaches them from
+// nn.Conv2d (newConvolution.py:129-133 layers, :149-158 forward calls, :184 backward).
+//
+// Two kernel families:
+//   * stencil (Cin == Cout == 1, small kH x kW): the memory-bound single-channel grid stencil of
+//     BASELINE config 3.  Every thread owns a 4-column strip and walks a contiguous range of the
+//     N*OH output rows with a kH-row register window, so each input row is read once per thread
+//     (plus kH-1 halo rows per range) with 16-byte row-major loads; the next row is prefetched
+//     while the current one is computed.  The row ranges are cut so that the launch fills the
+//     chip exactly once (no tail wave).  Algorithmic traffic: 8 B per grid point for forward,
+//     8 B for backward-weight+bias.
+//   * generic direct kernels for every other shape (correctness for the whole operator class).
+//
+// The weight-gradient reduction is wavefront-shuffle -> LDS -> float64 per-block partials in the
+// caller's workspace -> a fixed-order float64 finalize kernel (bitwise reproducible).
+#include "common.h"
+
+namespace {
+
+constexpr int BLOCK = 256;
+
+// ------------------------------------------------------------------------------------------
+// row segment loader: EXT = 4 + KW - 1 floats starting at column j0 of a W-wide row.
+template <int KW>
+__device__ __forceinline__ void load_row(float (&dst)[4 + KW - 1], const float *__restrict__ p,
+                                         int j0, int W)
+{
+    constexpr int EXT = 4 + KW - 1;
+    if (j0 + EXT <= W) {
+        const f4u v = *reinterpret_cast<const f4u *>(p);
+        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+        if constexpr (KW - 1 == 2) {
+            const f2u u = *reinterpret_cast<const f2u *>(p + 4);
+            dst[4] = u.x; dst[5] = u.y;
+        } else if constexpr (KW - 1 == 4) {
+            const f4u u = *reinterpret_cast<const f4u *>(p + 4);
+            dst[4] = u.x; dst[5] = u.y; dst[6] = u.z; dst[7] = u.w;
+        } else {
+#pragma unroll
+            for (int e = 4; e < EXT; ++e) dst[e] = p[e];
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < EXT; ++e) dst[e] = (j0 + e < W) ? p[e] : 0.0f;
+    }
+}
+
+__device__ __forceinline__ void load4_masked(float (&dst)[4], const float *__restrict__ p, int j0,
+                                             int OW)
+{
+    if (j0 + 4 <= OW) {
+        const f4u v = *reinterpret_cast<const f4u *>(p);
+        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[e] = (j0 + e < OW) ? p[e] : 0.0f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// stencil forward, Cin = Cout = 1.
+template <int KH, int KW>
+__global__ __launch_bounds__(BLOCK) void conv_fwd_c1_kernel(
+    const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ b,
+    float *__restrict__ y, int H, int W, int OH, int OW, int strips, long long total_rows,
+    int segs, int relu)
+{
+    constexpr int EXT = 4 + KW - 1;
+    const long long tid = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (tid >= (long long)strips * segs) return;
+    const int strip = (int)(tid % strips);
+    const int seg = (int)(tid / strips);
+    const long long r0 = total_rows * seg / segs;
+    const long long r1 = total_rows * (seg + 1) / segs;
+    if (r0 >= r1) return;
+    const int j0 = strip * 4;
+
+    float wr[KH][KW];
+#pragma unroll
+    for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < KW; ++kw) wr[kh][kw] = w[kh * KW + kw];
+    const float bias = b ? b[0] : 0.0f;
+
+    int n = (int)(r0 / OH);
+    int i = (int)(r0 - (long long)n * OH);
+    const float *xrow = x + ((size_t)n * H + i) * W + j0;   // input row i of image n, column j0
+    float *yrow = y + ((size_t)n * OH + i) * OW + j0;
+
+    float win[KH][EXT];
+    float pre[EXT];
+#pragma unroll
+    for (int kh = 0; kh < KH - 1; ++kh) load_row<KW>(win[kh], xrow + (size_t)kh * W, j0, W);
+    load_row<KW>(pre, xrow + (size_t)(KH - 1) * W, j0, W);
+
+    for (long long r = r0; r < r1; ++r) {
+#pragma unroll
+        for (int e = 0; e < EXT; ++e) win[KH - 1][e] = pre[e];
+        const bool last_of_image = (i + 1 == OH);
+        // prefetch the next input row (next output row of the same image)
+        if (r + 1 < r1 && !last_of_image) load_row<KW>(pre, xrow + (size_t)KH * W, j0, W);
+
+        float out[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float s = bias;
+#pragma unroll
+            for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < KW; ++kw) s = fmaf(wr[kh][kw], win[kh][q + kw], s);
+            out[q] = relu ? fmaxf(s, 0.0f) : s;
+        }
+        if (j0 + 4 <= OW) {
+            f4u v;
+            v.x = out[0]; v.y = out[1]; v.z = out[2]; v.w = out[3];
+            *reinterpret_cast<f4u *>(yrow) = v;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (j0 + q < OW) yrow[q] = out[q];
+        }
+#pragma unroll
+        for (int kh = 0; kh < KH - 1; ++kh)
+#pragma unroll
+            for (int e = 0; e < EXT; ++e) win[kh][e] = win[kh + 1][e];
+
+        yrow += OW;          // output rows of consecutive images are contiguous
+        if (!last_of_image) {
+            ++i;
+            xrow += W;
+        } else {
+            i = 0;
+            ++n;
+            xrow = x + (size_t)n * H * W + j0;
+            if (r + 1 < r1) {
+#pragma unroll
+                for (int kh = 0; kh < KH - 1; ++kh)
+                    load_row<KW>(win[kh], xrow + (size_t)kh * W, j0, W);
+                load_row<KW>(pre, xrow + (size_t)(KH - 1) * W, j0, W);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// stencil backward weight+bias, Cin = Cout = 1.  partial: [gridDim.x][KH*KW+1] float64.
+template <int KH, int KW>
+__global__ __launch_bounds__(BLOCK) void conv_bwd_wb_c1_kernel(
+    const float *__restrict__ x, const float *__restrict__ gy, double *__restrict__ partial,
+    int H, int W, int OH, int OW, int strips, long long total_rows, int segs)
+{
+    constexpr int EXT = 4 + KW - 1;
+    constexpr int NV = KH * KW + 1;
+    __shared__ float red[BLOCK / 64][NV];
+
+    float acc[KH][KW];
+    float accb = 0.0f;
+#pragma unroll
+    for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < KW; ++kw) acc[kh][kw] = 0.0f;
+
+    const long long tid = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    long long r0 = 0, r1 = 0;
+    int strip = 0;
+    if (tid < (long long)strips * segs) {
+        strip = (int)(tid % strips);
+        const int seg = (int)(tid / strips);
+        r0 = total_rows * seg / segs;
+        r1 = total_rows * (seg + 1) / segs;
+    }
+    if (r0 < r1) {
+        const int j0 = strip * 4;
+        int n = (int)(r0 / OH);
+        int i = (int)(r0 - (long long)n * OH);
+        const float *xrow = x + ((size_t)n * H + i) * W + j0;
+        const float *grow = gy + ((size_t)n * OH + i) * OW + j0;
+
+        float win[KH][EXT];
+        float pre[EXT];
+        float gpre[4];
+#pragma unroll
+        for (int kh = 0; kh < KH - 1; ++kh) load_row<KW>(win[kh], xrow + (size_t)kh * W, j0, W);
+        load_row<KW>(pre, xrow + (size_t)(KH - 1) * W, j0, W);
+        load4_masked(gpre, grow, j0, OW);
+
+        for (long long r = r0; r < r1; ++r) {
+            float g[4];
+#pragma unroll
+            for (int e = 0; e < EXT; ++e) win[KH - 1][e] = pre[e];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) g[q] = gpre[q];
+            const bool last_of_image = (i + 1 == OH);
+            if (r + 1 < r1) {
+                load4_masked(gpre, grow + OW, j0, OW);
+                if (!last_of_image) load_row<KW>(pre, xrow + (size_t)KH * W, j0, W);
+            }
+#pragma unroll
+            for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < KW; ++kw)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        acc[kh][kw] = fmaf(g[q], win[kh][q + kw], acc[kh][kw]);
+            accb += (g[0] + g[1]) + (g[2] + g[3]);
+#pragma unroll
+            for (int kh = 0; kh < KH - 1; ++kh)
+#pragma unroll
+                for (int e = 0; e < EXT; ++e) win[kh][e] = win[kh + 1][e];
+
+            grow += OW;
+            if (!last_of_image) {
+                ++i;
+                xrow += W;
+            } else {
+                i = 0;
+                ++n;
+                xrow = x + (size_t)n * H * W + j0;
+                if (r + 1 < r1) {
+#pragma unroll
+                    for (int kh = 0; kh < KH - 1; ++kh)
+                        load_row<KW>(win[kh], xrow + (size_t)kh * W, j0, W);
+                    load_row<KW>(pre, xrow + (size_t)(KH - 1) * W, j0, W);
+                }
+            }
+        }
+    }
+    // wavefront-shuffle reduction, then LDS across the block's 4 waves, float64 partial out.
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < KW; ++kw) {
+            const float s = wave_sum(acc[kh][kw]);
+            if (lane == 0) red[wv][kh * KW + kw] = s;
+        }
+    {
+        const float s = wave_sum(accb);
+        if (lane == 0) red[wv][NV - 1] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        double s = 0.0;
+#pragma unroll
+        for (int v = 0; v < BLOCK / 64; ++v) s += (double)red[v][threadIdx.x];
+        partial[(size_t)blockIdx.x * NV + threadIdx.x] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// fixed-order float64 reduction of per-block partials: one wave per output entry.
+// partial is [nparts][nent]; out_w gets entries [0, nw), out_b gets [nw, nent).
+__global__ __launch_bounds__(64) void reduce_partials_kernel(const double *__restrict__ partial,
+                                                            int nparts, int nent, int nw,
+                                                            float *__restrict__ out_w,
+                                                            float *__restrict__ out_b)
+{
+    const int e = blockIdx.x;
+    double s = 0.0;
+    for (int p = threadIdx.x; p < nparts; p += 64) s += partial[(size_t)p * nent + e];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) {
+        if (e < nw) out_w[e] = (float)s;
+        else if (out_b) out_b[e - nw] = (float)s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// generic direct forward: one thread = 4 consecutive outputs of one (n, o, i) row.
+__global__ __launch_bounds__(BLOCK) void conv_fwd_generic_kernel(
+    const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ b,
+    float *__restrict__ y, int N, int Cin, int H, int W, int Cout, int kH, int kW, int OH, int OW,
+    int strips, int relu)
+{
+    const long long total = (long long)N * Cout * OH * strips;
+    for (long long tid = (long long)blockIdx.x * BLOCK + threadIdx.x; tid < total;
+         tid += (long long)gridDim.x * BLOCK) {
+        const int strip = (int)(tid % strips);
+        long long t = tid / strips;
+        const int i = (int)(t % OH); t /= OH;
+        const int o = (int)(t % Cout);
+        const int n = (int)(t / Cout);
+        const int j0 = strip * 4;
+        const float bias = b ? b[o] : 0.0f;
+        float s0 = bias, s1 = bias, s2 = bias, s3 = bias;
+        for (int c = 0; c < Cin; ++c)
+            for (int kh = 0; kh < kH; ++kh) {
+                const float *xr = x + (((size_t)n * Cin + c) * H + i + kh) * W + j0;
+                const float *wr = w + (((size_t)o * Cin + c) * kH + kh) * kW;
+                float x0 = xr[0];
+                float x1 = (j0 + 1 < W) ? xr[1] : 0.0f;
+                float x2 = (j0 + 2 < W) ? xr[2] : 0.0f;
+                float x3 = (j0 + 3 < W) ? xr[3] : 0.0f;
+                for (int kw = 0; kw < kW; ++kw) {
+                    const float wv = wr[kw];
+                    s0 = fmaf(wv, x0, s0);
+                    s1 = fmaf(wv, x1, s1);
+                    s2 = fmaf(wv, x2, s2);
+                    s3 = fmaf(wv, x3, s3);
+                    x0 = x1; x1 = x2; x2 = x3;
+                    x3 = (j0 + 4 + kw < W) ? xr[4 + kw] : 0.0f;
+                }
+            }
+        float *yr = y + (((size_t)n * Cout + o) * OH + i) * OW + j0;
+        if (relu) { s0 = fmaxf(s0, 0.f); s1 = fmaxf(s1, 0.f); s2 = fmaxf(s2, 0.f); s3 = fmaxf(s3, 0.f); }
+        yr[0] = s0;
+        if (j0 + 1 < OW) yr[1] = s1;
+        if (j0 + 2 < OW) yr[2] = s2;
+        if (j0 + 3 < OW) yr[3] = s3;
+    }
+}
+
+// generic direct backward-data: one thread = one gx element.
+__global__ __launch_bounds__(BLOCK) void conv_bwd_data_generic_kernel(
+    const float *__restrict__ gy, const float *__restrict__ w, float *__restrict__ gx, int N,
+    int Cin, int H, int W, int Cout, int kH, int kW, int OH, int OW)
+{
+    const long long total = (long long)N * Cin * H * W;
+    for (long long tid = (long long)blockIdx.x * BLOCK + threadIdx.x; tid < total;
+         tid += (long long)gridDim.x * BLOCK) {
+        const int q = (int)(tid % W);
+        long long t = tid / W;
+        const int p = (int)(t % H); t /= H;
+        const int c = (int)(t % Cin);
+        const int n = (int)(t / Cin);
+        const int kh_lo = max(0, p - OH + 1), kh_hi = min(kH - 1, p);
+        const int kw_lo = max(0, q - OW + 1), kw_hi = min(kW - 1, q);
+        float s = 0.0f;
+        for (int o = 0; o < Cout; ++o)
+            for (int kh = kh_lo; kh <= kh_hi; ++kh) {
+                const float *gr = gy + (((size_t)n * Cout + o) * OH + (p - kh)) * OW + q;
+                const float *wr = w + (((size_t)o * Cin + c) * kH + kh) * kW;
+                for (int kw = kw_lo; kw <= kw_hi; ++kw) s = fmaf(wr[kw], gr[-kw], s);
+            }
+        gx[tid] = s;
+    }
+}
+
+// generic backward weight+bias: grid = (entries, splits); entry e < nw is a weight, else a bias.
+// Each block reduces its slice of the N*OH*OW positions; partial is [splits][nent] float64.
+__global__ __launch_bounds__(BLOCK) void conv_bwd_wb_generic_kernel(
+    const float *__restrict__ x, const float *__restrict__ gy, double *__restrict__ partial, int N,
+    int Cin, int H, int W, int Cout, int kH, int kW, int OH, int OW, int nw, int nent)
+{
+    __shared__ double red[BLOCK / 64];
+    const int e = blockIdx.x;
+    const int split = blockIdx.y, splits = gridDim.y;
+    const long long L = (long long)N * OH * OW;
+    const long long l0 = L * split / splits, l1 = L * (split + 1) / splits;
+    float s = 0.0f;
+    double sd = 0.0;
+    int cnt = 0;
+    if (e < nw) {
+        const int kw = e % kW;
+        const int kh = (e / kW) % kH;
+        const int c = (e / (kW * kH)) % Cin;
+        const int o = e / (kW * kH * Cin);
+        for (long long l = l0 + threadIdx.x; l < l1; l += BLOCK) {
+            const int j = (int)(l % OW);
+            const long long t = l / OW;
+            const int i = (int)(t % OH);
+            const int n = (int)(t / OH);
+            s = fmaf(gy[(((size_t)n * Cout + o) * OH + i) * OW + j],
+                     x[(((size_t)n * Cin + c) * H + i + kh) * W + j + kw], s);
+            if (++cnt == 256) { sd += (double)s; s = 0.0f; cnt = 0; }
+        }
+    } else {
+        const int o = e - nw;
+        for (long long l = l0 + threadIdx.x; l < l1; l += BLOCK) {
+            const int j = (int)(l % OW);
+            const long long t = l / OW;
+            const int i = (int)(t % OH);
+            const int n = (int)(t / OH);
+            s += gy[(((size_t)n * Cout + o) * OH + i) * OW + j];
+            if (++cnt == 256) { sd += (double)s; s = 0.0f; cnt = 0; }
+        }
+    }
+    sd += (double)s;
+    sd = wave_sum(sd);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sd;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tsum = 0.0;
+#pragma unroll
+        for (int v = 0; v < BLOCK / 64; ++v) tsum += red[v];
+        partial[(size_t)split * nent + e] = tsum;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+struct StencilPlan {
+    int strips, segs, blocks;
+    long long total_rows;
+};
+
+// Cut the N*OH output rows of every 4-column strip into `segs` contiguous ranges so that
+// strips*segs threads fill the chip once: blocks_per_cu resident blocks on every CU.
+template <typename K>
+int stencil_plan(K kernel, int N, int OH, int OW, StencilPlan *p)
+{
+    const int cus = wm_num_cus();
+    WM_REQUIRE(cus > 0, WM_ERR_NO_DEVICE, "no HIP device");
+    int occ = 0;
+    WM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, BLOCK, 0));
+    // the occupancy query can over-report by one block per CU (MI355X_MICROARCH, residency);
+    // a launch that is not fully resident doubles the kernel time, so stay one below it.
+    int bpc = occ - 1;
+    if (bpc > 6) bpc = 6;
+    if (bpc < 1) bpc = 1;
+    p->strips = (OW + 3) / 4;
+    p->total_rows = (long long)N * OH;
+    long long segs = (long long)cus * bpc * BLOCK / p->strips;
+    const long long max_segs = (p->total_rows + 7) / 8;   // at least ~8 rows per range
+    if (segs > max_segs) segs = max_segs;
+    if (segs < 1) segs = 1;
+    p->segs = (int)segs;
+    p->blocks = (int)(((long long)p->strips * segs + BLOCK - 1) / BLOCK);
+    return WM_OK;
+}
+
+bool stencil_shape(int Cin, int Cout, int kH, int kW, int OW)
+{
+    if (Cin != 1 || Cout != 1 || OW < 16) return false;
+    return (kH == 3 && kW == 3) || (kH == 5 && kW == 5) || (kH == 3 && kW == 1) ||
+           (kH == 1 && kW == 3) || (kH == 2 && kW == 1) || (kH == 1 && kW == 2) ||
+           (kH == 2 && kW == 2) || (kH == 1 && kW == 1);
+}
+
+#define WM_STENCIL_DISPATCH(MACRO)                  \
+    if (kH == 3 && kW == 3) { MACRO(3, 3) }         \
+    else if (kH == 5 && kW == 5) { MACRO(5, 5) }    \
+    else if (kH == 3 && kW == 1) { MACRO(3, 1) }    \
+    else if (kH == 1 && kW == 3) { MACRO(1, 3) }    \
+    else if (kH == 2 && kW == 1) { MACRO(2, 1) }    \
+    else if (kH == 1 && kW == 2) { MACRO(1, 2) }    \
+    else if (kH == 2 && kW == 2) { MACRO(2, 2) }    \
+    else { MACRO(1, 1) }
+
+int check_dims(int N, int Cin, int H, int W, int Cout, int kH, int kW)
+{
+    WM_REQUIRE(N > 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0 && kH > 0 && kW > 0, WM_ERR_INVALID,
+               "conv2d: non-positive dimension (N=%d Cin=%d H=%d W=%d Cout=%d kH=%d kW=%d)", N,
+               Cin, H, W, Cout, kH, kW);
+    WM_REQUIRE(kH <= H && kW <= W, WM_ERR_INVALID,
+               "conv2d: kernel (%d,%d) larger than input (%d,%d) -- valid padding has no output",
+               kH, kW, H, W);
+    return WM_OK;
+}
+
+int generic_grid(long long total)
+{
+    long long g = (total + BLOCK - 1) / BLOCK;
+    const long long cap = (long long)wm_num_cus() * 16;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+int bwd_wb_generic_splits(int N, int OH, int OW, int nent)
+{
+    const long long L = (long long)N * OH * OW;
+    long long s = (L + 16383) / 16384;
+    long long cap = (long long)wm_num_cus() * 8 / nent;
+    if (cap < 1) cap = 1;
+    if (s > cap) s = cap;
+    if (s < 1) s = 1;
+    if (s > 65535) s = 65535;
+    return (int)s;
+}
+
+}  // namespace
+
+extern "C" int wm_conv2d_fwd_f32(const float *x, const float *w, const float *b, float *y, int N,
+                                 int Cin, int H, int W, int Cout, int kH, int kW, int relu,
+                                 void *stream)
+{
+    WM_REQUIRE(x && w && y, WM_ERR_INVALID, "wm_conv2d_fwd_f32: null pointer");
+    if (int rc = check_dims(N, Cin, H, W, Cout, kH, kW)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int OH = H - kH + 1, OW = W - kW + 1;
+    if (stencil_shape(Cin, Cout, kH, kW, OW)) {
+#define FWD(KH_, KW_)                                                                       \
+    StencilPlan p;                                                                          \
+    if (int rc = stencil_plan(conv_fwd_c1_kernel<KH_, KW_>, N, OH, OW, &p)) return rc;      \
+    hipLaunchKernelGGL((conv_fwd_c1_kernel<KH_, KW_>), dim3(p.blocks), dim3(BLOCK), 0, st, x, \
+                       w, b, y, H, W, OH, OW, p.strips, p.total_rows, p.segs, relu);
+        WM_STENCIL_DISPATCH(FWD)
+#undef FWD
+        WM_LAUNCH_CHECK("conv_fwd_c1_kernel");
+        return WM_OK;
+    }
+    const int strips = (OW + 3) / 4;
+    const long long total = (long long)N * Cout * OH * strips;
+    hipLaunchKernelGGL(conv_fwd_generic_kernel, dim3(generic_grid(total)), dim3(BLOCK), 0, st, x,
+                       w, b, y, N, Cin, H, W, Cout, kH, kW, OH, OW, strips, relu);
+    WM_LAUNCH_CHECK("conv_fwd_generic_kernel");
+    return WM_OK;
+}
+
+extern "C" int wm_conv2d_bwd_data_f32(const float *gy, const float *w, float *gx, int N, int Cin,
+                                      int H, int W, int Cout, int kH, int kW, void *stream)
+{
+    WM_REQUIRE(gy && w && gx, WM_ERR_INVALID, "wm_conv2d_bwd_data_f32: null pointer");
+    if (int rc = check_dims(N, Cin, H, W, Cout, kH, kW)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int OH = H - kH + 1, OW = W - kW + 1;
+    const long long total = (long long)N * Cin * H * W;
+    hipLaunchKernelGGL(conv_bwd_data_generic_kernel, dim3(generic_grid(total)), dim3(BLOCK), 0, st,
+                       gy, w, gx, N, Cin, H, W, Cout, kH, kW, OH, OW);
+    WM_LAUNCH_CHECK("conv_bwd_data_generic_kernel");
+    return WM_OK;
+}
+
+extern "C" size_t wm_conv2d_bwd_wb_workspace_bytes(int N, int Cin, int H, int W, int Cout, int kH,
+                                                   int kW)
+{
+    if (N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || kH <= 0 || kW <= 0 || kH > H ||
+        kW > W)
+        return 0;
+    const int OH = H - kH + 1, OW = W - kW + 1;
+    const int nw = Cout * Cin * kH * kW, nent = nw + Cout;
+    if (stencil_shape(Cin, Cout, kH, kW, OW)) {
+        // upper bound on the stencil grid: 6 blocks per CU (stencil_plan) + 1
+        const size_t blocks = (size_t)wm_num_cus() * 6 + 1;
+        return wm_align_up(blocks * (size_t)nent * sizeof(double), 256);
+    }
+    const int splits = bwd_wb_generic_splits(N, OH, OW, nent);
+    return wm_align_up((size_t)splits * nent * sizeof(double), 256);
+}
+
+extern "C" int wm_conv2d_bwd_wb_f32(const float *x, const float *gy, float *gw, float *gb,
+                                    void *workspace, size_t workspace_bytes, int N, int Cin, int H,
+                                    int W, int Cout, int kH, int kW, void *stream)
+{
+    WM_REQUIRE(x && gy && gw, WM_ERR_INVALID, "wm_conv2d_bwd_wb_f32: null pointer");
+    if (int rc = check_dims(N, Cin, H, W, Cout, kH, kW)) return rc;
+    const size_t need = wm_conv2d_bwd_wb_workspace_bytes(N, Cin, H, W, Cout, kH, kW);
+    WM_REQUIRE(workspace && workspace_bytes >= need, WM_ERR_WORKSPACE,
+               "wm_conv2d_bwd_wb_f32: workspace of %zu bytes needed, %zu given", need,
+               workspace_bytes);
+    hipStream_t st = (hipStream_t)stream;
+    const int OH = H - kH + 1, OW = W - kW + 1;
+    const int nw = Cout * Cin * kH * kW, nent = nw + Cout;
+    double *partial = (double *)workspace;
+    int nparts = 0;
+    if (stencil_shape(Cin, Cout, kH, kW, OW)) {
+#define BWD(KH_, KW_)                                                                         \
+    StencilPlan p;                                                                            \
+    if (int rc = stencil_plan(conv_bwd_wb_c1_kernel<KH_, KW_>, N, OH, OW, &p)) return rc;     \
+    WM_REQUIRE((size_t)p.blocks * nent * sizeof(double) <= workspace_bytes, WM_ERR_WORKSPACE, \
+               "wm_conv2d_bwd_wb_f32: workspace too small for %d blocks", p.blocks);          \
+    hipLaunchKernelGGL((conv_bwd_wb_c1_kernel<KH_, KW_>), dim3(p.blocks), dim3(BLOCK), 0, st, \
+                       x, gy, partial, H, W, OH, OW, p.strips, p.total_rows, p.segs);         \
+    nparts = p.blocks;
+        WM_STENCIL_DISPATCH(BWD)
+#undef BWD
+        WM_LAUNCH_CHECK("conv_bwd_wb_c1_kernel");
+    } else {
+        const int splits = bwd_wb_generic_splits(N, OH, OW, nent);
+        hipLaunchKernelGGL(conv_bwd_wb_generic_kernel, dim3(nent, splits), dim3(BLOCK), 0, st, x,
+                           gy, partial, N, Cin, H, W, Cout, kH, kW, OH, OW, nw, nent);
+        WM_LAUNCH_CHECK("conv_bwd_wb_generic_kernel");
+        nparts = splits;
+    }
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(nent), dim3(64), 0, st, partial, nparts, nent,
+                       nw, gw, gb);
+    WM_LAUNCH_CHECK("reduce_partials_kernel");
+    return WM_OK;
+}

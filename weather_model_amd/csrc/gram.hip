@@ -1,0 +1,525 @@
+// gram.hip -- X'X / X'Y Gram build on fp32 MFMA, float64 combination, and the normal-equation solve.
+//
+// Replaces the iterative Adam/MSE fit of the reference's linear Dense stacks
+// (multipleRegression.py:273-298 + train_step :98-106; singleRegression.py:74-96) by the closed
+// form they converge to: ordinary least squares with intercept.  With Z = [X | 1 | Y] the whole
+// problem is the D x D Gram Z'Z (D = F+1+P); see include/wm.h.
+//
+// Kernels
+//   gram_f16_kernel     F = 16, P = 1 (BASELINE config 2).  HBM-bound: 68 B per row.  A wave reads
+//                       16 rows per 1 KiB dwordx4 load; lane 4s+a then holds features 4a..4a+3 of
+//                       row s, which is exactly the operand shape of v_mfma_f32_4x4x1_16b_f32
+//                       (16 independent 4x4 outer products, one per row): A = register r1,
+//                       B = register r2 gives Gram entries (4a+r1, 4b+r2).  The 10 register pairs
+//                       r1 <= r2 cover the symmetric 16x16 block with every MFMA flop useful and no
+//                       LDS round trip.  X'y, column sums, y'y are VALU FMAs on the same registers.
+//   gram_tile_kernel    any F, P.  One 16x16 tile of Z'Z per block column, v_mfma_f32_16x16x4_f32,
+//                       operands loaded straight from global memory (row-major rows are the
+//                       operand layout), rows split over blockIdx.y.
+//   both keep float32 sums for at most 1024 rows per accumulator, then add them into float64
+//   registers; per-block float64 partials go to the workspace and a finalize kernel adds them to
+//   acc in a fixed order.
+//   normal_solve_kernel one workgroup, float64 Cholesky of the centred system.
+#include "common.h"
+
+namespace {
+
+constexpr int BLOCK = 256;
+constexpr int WAVES = BLOCK / 64;
+
+// ---------------------------------------------------------------------------- F = 16, P = 1
+constexpr int F16_NPAIR = 10;                         // (r1,r2), r1 <= r2
+constexpr int F16_NVAL = F16_NPAIR * 4 + 4 + 4 + 2;   // per-lane values: 40 mfma + xy[4] + sx[4] + sy + syy
+constexpr int F16_PART = F16_NVAL * 4;                // per-block doubles (4 lane residues each)
+constexpr int F16_FLUSH_TILES = 1024;                 // 1024 tiles = 1024 products per accumulator
+constexpr int F16_UNROLL = 8;
+
+__device__ __forceinline__ constexpr int f16_pair(int r1, int r2)
+{
+    // index of (r1,r2), r1 <= r2, in the order (0,0)(0,1)(0,2)(0,3)(1,1)(1,2)(1,3)(2,2)(2,3)(3,3)
+    return r1 * 4 - (r1 * (r1 - 1)) / 2 + (r2 - r1);
+}
+
+struct F16Acc {
+    f32x4 g[F16_NPAIR];
+    float xy[4], sx[4], sy, syy;
+};
+
+__device__ __forceinline__ void f16_zero(F16Acc &a)
+{
+#pragma unroll
+    for (int p = 0; p < F16_NPAIR; ++p) a.g[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { a.xy[r] = 0.f; a.sx[r] = 0.f; }
+    a.sy = 0.f;
+    a.syy = 0.f;
+}
+
+__device__ __forceinline__ void f16_step(F16Acc &a, const f32x4 x, const float y)
+{
+    // 16 outer products per instruction: block s (lanes 4s..4s+3) is row s of the tile.
+    a.g[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(x.x, x.x, a.g[0], 0, 0, 0);
+    a.g[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(x.x, x.y, a.g[1], 0, 0, 0);
+    a.g[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(x.x, x.z, a.g[2], 0, 0, 0);
+    a.g[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(x.x, x.w, a.g[3], 0, 0, 0);
+    a.g[4] = __builtin_amdgcn_mfma_f32_4x4x1f32(x.y, x.y, a.g[4], 0, 0, 0);
+    a.g[5] = __builtin_amdgcn_mfma_f32_4x4x1f32(x.y, x.z, a.g[5], 0, 0, 0);
+    a.g[6] = __builtin_amdgcn_mfma_f32_4x4x1f32(x.y, x.w, a.g[6], 0, 0, 0);
+    a.g[7] = __builtin_amdgcn_mfma_f32_4x4x1f32(x.z, x.z, a.g[7], 0, 0, 0);
+    a.g[8] = __builtin_amdgcn_mfma_f32_4x4x1f32(x.z, x.w, a.g[8], 0, 0, 0);
+    a.g[9] = __builtin_amdgcn_mfma_f32_4x4x1f32(x.w, x.w, a.g[9], 0, 0, 0);
+    a.xy[0] = fmaf(x.x, y, a.xy[0]);
+    a.xy[1] = fmaf(x.y, y, a.xy[1]);
+    a.xy[2] = fmaf(x.z, y, a.xy[2]);
+    a.xy[3] = fmaf(x.w, y, a.xy[3]);
+    a.sx[0] += x.x;
+    a.sx[1] += x.y;
+    a.sx[2] += x.z;
+    a.sx[3] += x.w;
+    a.sy += y;
+    a.syy = fmaf(y, y, a.syy);
+}
+
+__device__ __forceinline__ void f16_flush(F16Acc &a, double (&d)[F16_NVAL])
+{
+#pragma unroll
+    for (int p = 0; p < F16_NPAIR; ++p)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d[p * 4 + r] += (double)a.g[p][r];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        d[40 + r] += (double)a.xy[r];
+        d[44 + r] += (double)a.sx[r];
+    }
+    d[48] += (double)a.sy;
+    d[49] += (double)a.syy;
+    f16_zero(a);
+}
+
+// partial: [gridDim.x][F16_NVAL][4] float64 (value index, lane residue lane&3).
+__global__ __launch_bounds__(BLOCK, 2) void gram_f16_kernel(const float *__restrict__ X,
+                                                            const float *__restrict__ Y,
+                                                            long long n,
+                                                            double *__restrict__ partial)
+{
+    __shared__ double red[WAVES][F16_NVAL][4];
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const long long nwaves = (long long)gridDim.x * WAVES;
+    const long long wave_id = (long long)blockIdx.x * WAVES + wv;
+    const long long tiles = (n + 15) >> 4;          // 16-row tiles, the last may be partial
+    const long long full_tiles = n >> 4;
+    const long long t0 = tiles * wave_id / nwaves;
+    const long long t1 = tiles * (wave_id + 1) / nwaves;
+
+    F16Acc a;
+    f16_zero(a);
+    double d[F16_NVAL];
+#pragma unroll
+    for (int v = 0; v < F16_NVAL; ++v) d[v] = 0.0;
+
+    const f32x4 *__restrict__ Xv = reinterpret_cast<const f32x4 *>(X);
+    const int rsub = lane >> 2;
+    long long t = t0;
+    int since_flush = 0;
+    const long long t1_full = (t1 < full_tiles) ? t1 : full_tiles;
+    for (; t + F16_UNROLL <= t1_full; t += F16_UNROLL) {
+        f32x4 xv[F16_UNROLL];
+        float yv[F16_UNROLL];
+#pragma unroll
+        for (int u = 0; u < F16_UNROLL; ++u) {
+            xv[u] = Xv[(t + u) * 64 + lane];
+            yv[u] = Y[(t + u) * 16 + rsub];
+        }
+#pragma unroll
+        for (int u = 0; u < F16_UNROLL; ++u) f16_step(a, xv[u], yv[u]);
+        since_flush += F16_UNROLL;
+        if (since_flush >= F16_FLUSH_TILES) {
+            f16_flush(a, d);
+            since_flush = 0;
+        }
+    }
+    for (; t < t1; ++t) {
+        const long long row = t * 16 + rsub;
+        f32x4 xv = (f32x4){0.f, 0.f, 0.f, 0.f};
+        float yv = 0.f;
+        if (row < n) {
+            xv = Xv[t * 64 + lane];
+            yv = Y[row];
+        }
+        f16_step(a, xv, yv);
+    }
+    f16_flush(a, d);
+
+    // sum the 16 lane blocks (rows) of the wave: lanes with equal lane&3 hold the same entries
+#pragma unroll
+    for (int v = 0; v < F16_NVAL; ++v) {
+        double s = d[v];
+        s += __shfl_xor(s, 4, 64);
+        s += __shfl_xor(s, 8, 64);
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        if (lane < 4) red[wv][v][lane] = s;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < F16_PART; i += BLOCK) {
+        const int v = i >> 2, b = i & 3;
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) s += red[w][v][b];
+        partial[(size_t)blockIdx.x * F16_PART + i] = s;
+    }
+}
+
+// acc (18x18) += fixed-order sum of the per-block partials.  One wave per acc entry.
+__global__ __launch_bounds__(64) void gram_f16_finalize_kernel(const double *__restrict__ partial,
+                                                               int nparts, long long n,
+                                                               double *__restrict__ acc)
+{
+    constexpr int D = 18;
+    const int e = blockIdx.x;
+    const int i = e / D, j = e % D;
+    int idx = -1;   // index into the F16_PART values of one block
+    if (i < 16 && j < 16) {
+        const int a = i >> 2, r1 = i & 3, b = j >> 2, r2 = j & 3;
+        // mfma(A = reg r1, B = reg r2): register a', lane residue b' holds
+        //   sum_rows X[row][4a'+r1] * X[row][4b'+r2]
+        if (r1 <= r2) idx = (f16_pair(r1, r2) * 4 + a) * 4 + b;
+        else          idx = (f16_pair(r2, r1) * 4 + b) * 4 + a;
+    } else if (i < 16 && j == 16) idx = (44 + (i & 3)) * 4 + (i >> 2);
+    else if (j < 16 && i == 16) idx = (44 + (j & 3)) * 4 + (j >> 2);
+    else if (i < 16 && j == 17) idx = (40 + (i & 3)) * 4 + (i >> 2);
+    else if (j < 16 && i == 17) idx = (40 + (j & 3)) * 4 + (j >> 2);
+    else if ((i == 16 && j == 17) || (i == 17 && j == 16)) idx = 48 * 4;   // sum y (residue 0)
+    else if (i == 17 && j == 17) idx = 49 * 4;                             // sum y^2
+    double s = 0.0;
+    if (idx >= 0) {
+        for (int p = threadIdx.x; p < nparts; p += 64) s += partial[(size_t)p * F16_PART + idx];
+        s = wave_sum(s);
+    } else {
+        s = (double)n;   // (16,16): the row count
+    }
+    if (threadIdx.x == 0) acc[e] += s;
+}
+
+// ---------------------------------------------------------------------------- generic tiles
+__device__ __forceinline__ float zval(const float *__restrict__ X, const float *__restrict__ Y,
+                                      long long row, int col, long long n, int F, int P, int D)
+{
+    if (row >= n || col >= D) return 0.0f;
+    if (col < F) return X[row * F + col];
+    if (col == F) return 1.0f;
+    return Y[row * P + (col - F - 1)];
+}
+
+constexpr int TILE_FLUSH_STEPS = 256;   // 256 steps x 4 rows = 1024 products per accumulator
+
+// grid = (tile pairs (ti <= tj), row slices).  partial: [slices][pairs][256] float64, element
+// index reg*64 + lane of the 16x16x4 accumulator (row = (lane>>4)*4 + reg, col = lane&15).
+__global__ __launch_bounds__(BLOCK) void gram_tile_kernel(const float *__restrict__ X,
+                                                          const float *__restrict__ Y, long long n,
+                                                          int F, int P, int DT,
+                                                          double *__restrict__ partial)
+{
+    __shared__ double red[WAVES][4][64];
+    const int D = F + 1 + P;
+    // decode the upper-triangular pair index
+    int pair = blockIdx.x, ti = 0;
+    while (pair >= DT - ti) { pair -= DT - ti; ++ti; }
+    const int tj = ti + pair;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long steps = (n + 3) >> 2;
+    const long long nchunks = (long long)gridDim.y * WAVES;
+    const long long chunk = (long long)blockIdx.y * WAVES + wv;
+    const long long s0 = steps * chunk / nchunks, s1 = steps * (chunk + 1) / nchunks;
+    const int k = lane >> 4;
+    const int ca = ti * 16 + (lane & 15), cb = tj * 16 + (lane & 15);
+    const bool diag = (ti == tj);
+
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    double d[4] = {0.0, 0.0, 0.0, 0.0};
+    int since = 0;
+    long long s = s0;
+    for (; s + 4 <= s1; s += 4) {
+        float av[4], bv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long row = (s + u) * 4 + k;
+            av[u] = zval(X, Y, row, ca, n, F, P, D);
+            bv[u] = diag ? av[u] : zval(X, Y, row, cb, n, F, P, D);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+        since += 4;
+        if (since >= TILE_FLUSH_STEPS) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { d[r] += (double)acc[r]; acc[r] = 0.f; }
+            since = 0;
+        }
+    }
+    for (; s < s1; ++s) {
+        const long long row = s * 4 + k;
+        const float av = zval(X, Y, row, ca, n, F, P, D);
+        const float bv = diag ? av : zval(X, Y, row, cb, n, F, P, D);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        d[r] += (double)acc[r];
+        red[wv][r][lane] = d[r];
+    }
+    __syncthreads();
+    {
+        const int r = threadIdx.x >> 6, l = threadIdx.x & 63;
+        double sum = 0.0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) sum += red[w][r][l];
+        partial[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x] = sum;
+    }
+}
+
+// grid = pairs, 256 threads: thread = one accumulator element; sums the slices in order.
+__global__ __launch_bounds__(BLOCK) void gram_tile_finalize_kernel(
+    const double *__restrict__ partial, int slices, int npairs, int DT, int D,
+    double *__restrict__ acc)
+{
+    int pair = blockIdx.x, ti = 0;
+    while (pair >= DT - ti) { pair -= DT - ti; ++ti; }
+    const int tj = ti + pair;
+    const int reg = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int gi = ti * 16 + (lane >> 4) * 4 + reg;
+    const int gj = tj * 16 + (lane & 15);
+    if (gi >= D || gj >= D) return;
+    double s = 0.0;
+    for (int sl = 0; sl < slices; ++sl)
+        s += partial[((size_t)sl * npairs + blockIdx.x) * 256 + threadIdx.x];
+    acc[(size_t)gi * D + gj] += s;
+    if (ti != tj) acc[(size_t)gj * D + gi] += s;
+}
+
+// ---------------------------------------------------------------------------- solve
+// One workgroup.  A (F x F) and B (F x P) live in LDS when they fit, else in the workspace.
+template <bool USE_LDS>
+__global__ __launch_bounds__(BLOCK) void normal_solve_kernel(const double *__restrict__ acc, int F,
+                                                             int P, int fit_intercept, double ridge,
+                                                             double *__restrict__ beta,
+                                                             int *__restrict__ status,
+                                                             double *__restrict__ ws)
+{
+    // all LDS in the dynamic region (16-byte aligned base): 2 doubles of flags, then A and B
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    volatile int &bad = *reinterpret_cast<volatile int *>(smem);
+    const int D = F + 1 + P;
+    double *A = USE_LDS ? smem + 2 : ws;
+    double *B = A + (size_t)F * F;
+    const int tid = threadIdx.x;
+    const double n = acc[(size_t)F * D + F];
+    const double inv_n = (fit_intercept && n > 0.0) ? 1.0 / n : 0.0;
+    if (tid == 0) bad = (fit_intercept && !(n > 0.0)) ? 1 : 0;
+    for (int e = tid; e < F * F; e += BLOCK) {
+        const int i = e / F, j = e % F;
+        double v = acc[(size_t)i * D + j] - acc[(size_t)i * D + F] * acc[(size_t)j * D + F] * inv_n;
+        if (i == j) v += ridge;
+        A[e] = v;
+    }
+    for (int e = tid; e < F * P; e += BLOCK) {
+        const int i = e / P, p = e % P;
+        B[e] = acc[(size_t)i * D + F + 1 + p] -
+               acc[(size_t)i * D + F] * acc[(size_t)F * D + F + 1 + p] * inv_n;
+    }
+    __syncthreads();
+    // right-looking Cholesky, lower triangle in place
+    for (int k = 0; k < F; ++k) {
+        if (tid == 0) {
+            const double dk = A[(size_t)k * F + k];
+            if (!(dk > 0.0)) bad = 1;
+            A[(size_t)k * F + k] = sqrt(dk > 0.0 ? dk : 1.0);
+        }
+        __syncthreads();
+        if (bad) break;
+        const double dk = A[(size_t)k * F + k];
+        for (int i = k + 1 + tid; i < F; i += BLOCK) A[(size_t)i * F + k] /= dk;
+        __syncthreads();
+        const int m = F - k - 1;
+        for (int e = tid; e < m * m; e += BLOCK) {
+            const int i = k + 1 + e / m, j = k + 1 + e % m;
+            if (j <= i) A[(size_t)i * F + j] -= A[(size_t)i * F + k] * A[(size_t)j * F + k];
+        }
+        __syncthreads();
+    }
+    if (!bad) {
+        // forward substitution L z = B (column oriented), then back substitution L' beta = z
+        for (int k = 0; k < F; ++k) {
+            const double dk = A[(size_t)k * F + k];
+            for (int p = tid; p < P; p += BLOCK) B[(size_t)k * P + p] /= dk;
+            __syncthreads();
+            const int m = F - k - 1;
+            for (int e = tid; e < m * P; e += BLOCK) {
+                const int i = k + 1 + e / P, p = e % P;
+                B[(size_t)i * P + p] -= A[(size_t)i * F + k] * B[(size_t)k * P + p];
+            }
+            __syncthreads();
+        }
+        for (int k = F - 1; k >= 0; --k) {
+            const double dk = A[(size_t)k * F + k];
+            for (int p = tid; p < P; p += BLOCK) B[(size_t)k * P + p] /= dk;
+            __syncthreads();
+            for (int e = tid; e < k * P; e += BLOCK) {
+                const int i = e / P, p = e % P;
+                B[(size_t)i * P + p] -= A[(size_t)k * F + i] * B[(size_t)k * P + p];
+            }
+            __syncthreads();
+        }
+    }
+    const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+    for (int e = tid; e < F * P; e += BLOCK) beta[e] = bad ? qnan : B[e];
+    __syncthreads();
+    for (int p = tid; p < P; p += BLOCK) {
+        double icpt = 0.0;
+        if (fit_intercept && !bad) {
+            icpt = acc[(size_t)F * D + F + 1 + p] * inv_n;
+            for (int i = 0; i < F; ++i) icpt -= acc[(size_t)i * D + F] * inv_n * B[(size_t)i * P + p];
+        }
+        beta[(size_t)F * P + p] = bad ? qnan : icpt;
+    }
+    if (tid == 0 && status) *status = bad;
+}
+
+__global__ __launch_bounds__(BLOCK) void linear_predict_kernel(const float *__restrict__ X,
+                                                              const double *__restrict__ beta,
+                                                              float *__restrict__ Yhat,
+                                                              long long n, int F, int P)
+{
+    const long long total = n * P;
+    for (long long t = (long long)blockIdx.x * BLOCK + threadIdx.x; t < total;
+         t += (long long)gridDim.x * BLOCK) {
+        const long long r = t / P;
+        const int p = (int)(t % P);
+        double s = beta[(size_t)F * P + p];
+        for (int f = 0; f < F; ++f) s += (double)X[r * F + f] * beta[(size_t)f * P + p];
+        Yhat[t] = (float)s;
+    }
+}
+
+// ---------------------------------------------------------------------------- planning
+bool use_f16(const float *X, int F, int P)
+{
+    return F == 16 && P == 1 && (((uintptr_t)X) & 15) == 0;
+}
+
+int f16_grid()
+{
+    // 2 waves per SIMD (launch bounds) = 2 blocks of 4 waves per CU; every block is resident.
+    return wm_num_cus() * 2;
+}
+
+void tile_plan(long long n, int F, int P, int *DT, int *pairs, int *slices)
+{
+    const int D = F + 1 + P;
+    *DT = (D + 15) / 16;
+    *pairs = *DT * (*DT + 1) / 2;
+    long long s = ((long long)wm_num_cus() * 8 + *pairs - 1) / *pairs;
+    const long long max_s = (n + 4095) / 4096;
+    if (s > max_s) s = max_s;
+    if (s < 1) s = 1;
+    if (s > 65535) s = 65535;
+    *slices = (int)s;
+}
+
+constexpr size_t SOLVE_LDS_LIMIT = 48 * 1024;
+
+}  // namespace
+
+extern "C" size_t wm_gram_workspace_bytes(int64_t n, int F, int P)
+{
+    if (n <= 0 || F <= 0 || P <= 0 || wm_num_cus() <= 0) return 0;
+    int DT, pairs, slices;
+    tile_plan(n, F, P, &DT, &pairs, &slices);
+    size_t b = (size_t)slices * pairs * 256 * sizeof(double);
+    if (F == 16 && P == 1) {
+        const size_t b16 = (size_t)f16_grid() * F16_PART * sizeof(double);
+        if (b16 > b) b = b16;
+    }
+    return wm_align_up(b, 256);
+}
+
+extern "C" int wm_gram_f32(const float *X, const float *Y, int64_t n, int F, int P, double *acc,
+                           void *workspace, size_t workspace_bytes, void *stream)
+{
+    WM_REQUIRE(X && Y && acc, WM_ERR_INVALID, "wm_gram_f32: null pointer");
+    WM_REQUIRE(F > 0 && P > 0 && n >= 0, WM_ERR_INVALID, "wm_gram_f32: bad sizes n=%lld F=%d P=%d",
+               (long long)n, F, P);
+    if (n == 0) return WM_OK;
+    WM_REQUIRE(wm_num_cus() > 0, WM_ERR_NO_DEVICE, "wm_gram_f32: no HIP device");
+    const size_t need = wm_gram_workspace_bytes(n, F, P);
+    WM_REQUIRE(workspace && workspace_bytes >= need, WM_ERR_WORKSPACE,
+               "wm_gram_f32: workspace of %zu bytes needed, %zu given", need, workspace_bytes);
+    hipStream_t st = (hipStream_t)stream;
+    double *partial = (double *)workspace;
+    if (use_f16(X, F, P)) {
+        const int grid = f16_grid();
+        hipLaunchKernelGGL(gram_f16_kernel, dim3(grid), dim3(BLOCK), 0, st, X, Y, (long long)n,
+                           partial);
+        WM_LAUNCH_CHECK("gram_f16_kernel");
+        hipLaunchKernelGGL(gram_f16_finalize_kernel, dim3(18 * 18), dim3(64), 0, st, partial, grid,
+                           (long long)n, acc);
+        WM_LAUNCH_CHECK("gram_f16_finalize_kernel");
+        return WM_OK;
+    }
+    int DT, pairs, slices;
+    tile_plan(n, F, P, &DT, &pairs, &slices);
+    hipLaunchKernelGGL(gram_tile_kernel, dim3(pairs, slices), dim3(BLOCK), 0, st, X, Y,
+                       (long long)n, F, P, DT, partial);
+    WM_LAUNCH_CHECK("gram_tile_kernel");
+    hipLaunchKernelGGL(gram_tile_finalize_kernel, dim3(pairs), dim3(BLOCK), 0, st, partial, slices,
+                       pairs, DT, F + 1 + P, acc);
+    WM_LAUNCH_CHECK("gram_tile_finalize_kernel");
+    return WM_OK;
+}
+
+extern "C" size_t wm_normal_solve_workspace_bytes(int F, int P)
+{
+    if (F <= 0 || P <= 0) return 0;
+    const size_t b = ((size_t)F * F + (size_t)F * P) * sizeof(double);
+    return b <= SOLVE_LDS_LIMIT ? 0 : wm_align_up(b, 256);
+}
+
+extern "C" int wm_normal_solve_f64(const double *acc, int F, int P, int fit_intercept, double ridge,
+                                   double *beta, int *status, void *workspace,
+                                   size_t workspace_bytes, void *stream)
+{
+    WM_REQUIRE(acc && beta, WM_ERR_INVALID, "wm_normal_solve_f64: null pointer");
+    WM_REQUIRE(F > 0 && P > 0, WM_ERR_INVALID, "wm_normal_solve_f64: bad sizes F=%d P=%d", F, P);
+    WM_REQUIRE(ridge >= 0.0, WM_ERR_INVALID, "wm_normal_solve_f64: negative ridge");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t bytes = ((size_t)F * F + (size_t)F * P) * sizeof(double);
+    if (bytes <= SOLVE_LDS_LIMIT) {
+        hipLaunchKernelGGL(normal_solve_kernel<true>, dim3(1), dim3(BLOCK), bytes + 16, st, acc, F, P,
+                           fit_intercept, ridge, beta, status, (double *)nullptr);
+    } else {
+        const size_t need = wm_normal_solve_workspace_bytes(F, P);
+        WM_REQUIRE(workspace && workspace_bytes >= need, WM_ERR_WORKSPACE,
+                   "wm_normal_solve_f64: workspace of %zu bytes needed, %zu given", need,
+                   workspace_bytes);
+        hipLaunchKernelGGL(normal_solve_kernel<false>, dim3(1), dim3(BLOCK), 16, st, acc, F, P,
+                           fit_intercept, ridge, beta, status, (double *)workspace);
+    }
+    WM_LAUNCH_CHECK("normal_solve_kernel");
+    return WM_OK;
+}
+
+extern "C" int wm_linear_predict_f32(const float *X, const double *beta, float *Yhat, int64_t n,
+                                     int F, int P, void *stream)
+{
+    WM_REQUIRE(X && beta && Yhat, WM_ERR_INVALID, "wm_linear_predict_f32: null pointer");
+    WM_REQUIRE(F > 0 && P > 0 && n >= 0, WM_ERR_INVALID, "wm_linear_predict_f32: bad sizes");
+    if (n == 0) return WM_OK;
+    long long g = ((long long)n * P + BLOCK - 1) / BLOCK;
+    const long long cap = (long long)wm_num_cus() * 16;
+    if (g > cap) g = cap;
+    hipLaunchKernelGGL(linear_predict_kernel, dim3((int)g), dim3(BLOCK), 0, (hipStream_t)stream, X,
+                       beta, Yhat, (long long)n, F, P);
+    WM_LAUNCH_CHECK("linear_predict_kernel");
+    return WM_OK;
+}

@@ -1,0 +1,250 @@
+"""Operator layer: PyTorch-ROCm tensors -> ctypes -> libwm.so (hand-written gfx950 HIP).
+
+Mirrors the two library operators the reference's hot path calls:
+  * ``conv2d`` / ``Conv2dFunction``  <-> torch.nn.functional.conv2d as reached from nn.Conv2d
+    (newConvolution.py:129-133,149-158) and its autograd (loss.backward(), :184)
+  * ``gram`` / ``normal_solve`` / ``lstsq_fit`` <-> the least-squares problem the linear Dense
+    stacks minimise (multipleRegression.py:273-298, singleRegression.py:74-96)
+
+PyTorch is plumbing only (device memory, streams).  Every op requires CUDA(HIP) tensors and
+raises otherwise -- there is no CPU path in the product.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _req(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on the GPU (weather_model_amd has no CPU fallback)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    return t.contiguous()
+
+
+def _conv_dims(x, w):
+    if x.dim() != 4 or w.dim() != 4:
+        raise ValueError(f"conv2d expects NCHW input and (Cout,Cin,kH,kW) weight, got "
+                         f"{tuple(x.shape)} and {tuple(w.shape)}")
+    N, Cin, H, W = x.shape
+    Cout, Cin2, kH, kW = w.shape
+    if Cin != Cin2:
+        # same error class torch raises for a channel mismatch
+        raise RuntimeError(f"conv2d: expected input with {Cin2} channels, got {Cin}")
+    if kH > H or kW > W:
+        raise RuntimeError(f"conv2d: kernel size ({kH},{kW}) can't be greater than input ({H},{W})")
+    return N, Cin, H, W, Cout, kH, kW
+
+
+def conv2d_forward(x, w, b=None, relu=False):
+    x, w = _req(x, "input"), _req(w, "weight")
+    b = None if b is None else _req(b, "bias")
+    N, Cin, H, W, Cout, kH, kW = _conv_dims(x, w)
+    y = torch.empty((N, Cout, H - kH + 1, W - kW + 1), device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().wm_conv2d_fwd_f32(
+            x.data_ptr(), w.data_ptr(), 0 if b is None else b.data_ptr(), y.data_ptr(),
+            N, Cin, H, W, Cout, kH, kW, int(bool(relu)), _stream()))
+    return y
+
+
+def conv2d_backward_data(gy, w, x_shape):
+    gy, w = _req(gy, "grad_output"), _req(w, "weight")
+    N, Cin, H, W = x_shape
+    Cout, _, kH, kW = w.shape
+    gx = torch.empty((N, Cin, H, W), device=gy.device, dtype=torch.float32)
+    with torch.cuda.device(gy.device):
+        _lib.check(_lib.lib().wm_conv2d_bwd_data_f32(
+            gy.data_ptr(), w.data_ptr(), gx.data_ptr(), N, Cin, H, W, Cout, kH, kW, _stream()))
+    return gx
+
+
+def conv2d_backward_wb(x, gy, w_shape, need_bias=True):
+    x, gy = _req(x, "input"), _req(gy, "grad_output")
+    N, Cin, H, W = x.shape
+    Cout, _, kH, kW = w_shape
+    L = _lib.lib()
+    with torch.cuda.device(x.device):
+        nbytes = L.wm_conv2d_bwd_wb_workspace_bytes(N, Cin, H, W, Cout, kH, kW)
+        ws = torch.empty((max(nbytes, 8),), device=x.device, dtype=torch.uint8)
+        gw = torch.empty(tuple(w_shape), device=x.device, dtype=torch.float32)
+        gb = torch.empty((Cout,), device=x.device, dtype=torch.float32) if need_bias else None
+        _lib.check(L.wm_conv2d_bwd_wb_f32(
+            x.data_ptr(), gy.data_ptr(), gw.data_ptr(), 0 if gb is None else gb.data_ptr(),
+            ws.data_ptr(), ws.numel(), N, Cin, H, W, Cout, kH, kW, _stream()))
+    return gw, gb
+
+
+class Conv2dFunction(torch.autograd.Function):
+    """autograd node so ``loss.backward()`` at the reference call site (newConvolution.py:184)
+    reaches the HIP backward kernels."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return conv2d_forward(x, w, b)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = conv2d_backward_data(gy, w, x.shape) if ctx.needs_input_grad[0] else None
+        gw = gb = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            gw, gb = conv2d_backward_wb(x, gy, w.shape, need_bias=ctx.has_bias)
+        return gx, gw, gb
+
+
+def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
+    """Drop-in for ``torch.nn.functional.conv2d`` restricted to the convention every reference
+    call uses (stride 1, no padding, dilation 1, groups 1); accepts the unbatched (C,H,W) input
+    the reference passes (newConvolution.py:149)."""
+    def _one(v):
+        return v if isinstance(v, int) else (v[0] if len(set(v)) == 1 else None)
+    if _one(stride) != 1 or _one(padding) != 0 or _one(dilation) != 1 or groups != 1:
+        raise NotImplementedError("weather_model_amd.conv2d implements stride=1, padding=0, "
+                                  "dilation=1, groups=1 (the reference's convention) only")
+    unbatched = input.dim() == 3
+    x = input.unsqueeze(0) if unbatched else input
+    y = Conv2dFunction.apply(x, weight, bias)
+    return y.squeeze(0) if unbatched else y
+
+
+# --------------------------------------------------------------------------- least squares
+
+def gram(X, Y, acc=None):
+    """acc (D x D float64, D = F+1+P) += [X|1|Y]' [X|1|Y].  acc is created zeroed if None."""
+    X = _req(X, "X")
+    Y = _req(Y, "Y")
+    if X.dim() != 2:
+        raise ValueError(f"X must be (n, F), got {tuple(X.shape)}")
+    if Y.dim() == 1:
+        Y = Y[:, None]
+    if Y.dim() != 2 or Y.shape[0] != X.shape[0]:
+        raise ValueError(f"Y must be (n, P) with n={X.shape[0]}, got {tuple(Y.shape)}")
+    Y = Y.contiguous()
+    n, F = X.shape
+    P = Y.shape[1]
+    if F < 1 or P < 1:
+        raise ValueError("gram needs at least one feature and one target column")
+    D = F + 1 + P
+    if acc is None:
+        acc = torch.zeros((D, D), device=X.device, dtype=torch.float64)
+    else:
+        if acc.shape != (D, D) or acc.dtype != torch.float64 or not acc.is_cuda or \
+                not acc.is_contiguous():
+            raise ValueError(f"acc must be a contiguous CUDA float64 ({D},{D}) tensor")
+    if n == 0:
+        return acc
+    L = _lib.lib()
+    with torch.cuda.device(X.device):
+        nbytes = L.wm_gram_workspace_bytes(n, F, P)
+        ws = torch.empty((max(nbytes, 8),), device=X.device, dtype=torch.uint8)
+        _lib.check(L.wm_gram_f32(X.data_ptr(), Y.data_ptr(), n, F, P, acc.data_ptr(),
+                                 ws.data_ptr(), ws.numel(), _stream()))
+    return acc
+
+
+class GramPlan:
+    """Pre-allocated workspace for repeated Gram builds of one shape (no per-call allocation)."""
+
+    def __init__(self, n, F, P, device):
+        self.n, self.F, self.P = int(n), int(F), int(P)
+        self.device = torch.device(device)
+        L = _lib.lib()
+        with torch.cuda.device(self.device):
+            nbytes = L.wm_gram_workspace_bytes(self.n, self.F, self.P)
+        self.ws = torch.empty((max(nbytes, 8),), device=self.device, dtype=torch.uint8)
+        D = F + 1 + P
+        self.acc = torch.zeros((D, D), device=self.device, dtype=torch.float64)
+        self.beta = torch.empty((F + 1, P), device=self.device, dtype=torch.float64)
+        self.status = torch.zeros((1,), device=self.device, dtype=torch.int32)
+        sb = L.wm_normal_solve_workspace_bytes(self.F, self.P)
+        self.solve_ws = torch.empty((max(sb, 8),), device=self.device, dtype=torch.uint8)
+
+    def accumulate(self, X, Y):
+        L = _lib.lib()
+        _lib.check(L.wm_gram_f32(X.data_ptr(), Y.data_ptr(), self.n, self.F, self.P,
+                                 self.acc.data_ptr(), self.ws.data_ptr(), self.ws.numel(),
+                                 _stream()))
+
+    def solve(self, fit_intercept=True, ridge=0.0):
+        L = _lib.lib()
+        _lib.check(L.wm_normal_solve_f64(self.acc.data_ptr(), self.F, self.P,
+                                         int(bool(fit_intercept)), float(ridge),
+                                         self.beta.data_ptr(), self.status.data_ptr(),
+                                         self.solve_ws.data_ptr(), self.solve_ws.numel(),
+                                         _stream()))
+        return self.beta
+
+
+def normal_solve(acc, F, P, fit_intercept=True, ridge=0.0, check=True):
+    """beta ((F+1) x P float64, intercept last) from the Gram ``acc``."""
+    D = F + 1 + P
+    if acc.shape != (D, D) or acc.dtype != torch.float64 or not acc.is_cuda:
+        raise ValueError(f"acc must be a CUDA float64 ({D},{D}) tensor")
+    acc = acc.contiguous()
+    L = _lib.lib()
+    beta = torch.empty((F + 1, P), device=acc.device, dtype=torch.float64)
+    status = torch.zeros((1,), device=acc.device, dtype=torch.int32)
+    with torch.cuda.device(acc.device):
+        nbytes = L.wm_normal_solve_workspace_bytes(F, P)
+        ws = torch.empty((max(nbytes, 8),), device=acc.device, dtype=torch.uint8)
+        _lib.check(L.wm_normal_solve_f64(acc.data_ptr(), F, P, int(bool(fit_intercept)),
+                                         float(ridge), beta.data_ptr(), status.data_ptr(),
+                                         ws.data_ptr(), ws.numel(), _stream()))
+    if check and int(status.item()) != 0:
+        raise RuntimeError("normal equations are not positive definite (collinear features or "
+                           "no rows); pass ridge > 0")
+    return beta
+
+
+def lstsq_fit(X, Y, fit_intercept=True, ridge=0.0):
+    Yv = Y if Y.dim() == 2 else Y[:, None]
+    acc = gram(X, Yv)
+    return normal_solve(acc, X.shape[1], Yv.shape[1], fit_intercept, ridge)
+
+
+def linear_predict(X, beta):
+    X = _req(X, "X")
+    beta = _req(beta, "beta", torch.float64)
+    n, F = X.shape
+    P = beta.shape[1]
+    if beta.shape[0] != F + 1:
+        raise ValueError(f"beta must be ({F + 1}, P), got {tuple(beta.shape)}")
+    out = torch.empty((n, P), device=X.device, dtype=torch.float32)
+    with torch.cuda.device(X.device):
+        _lib.check(_lib.lib().wm_linear_predict_f32(X.data_ptr(), beta.data_ptr(), out.data_ptr(),
+                                                    n, F, P, _stream()))
+    return out
+
+
+# --------------------------------------------------------------------------- synthetic data
+
+def synth_uniform(shape, seed, lo=0.0, hi=1.0, offset=0, device="cuda"):
+    out = torch.empty(shape, device=device, dtype=torch.float32)
+    with torch.cuda.device(out.device):
+        _lib.check(_lib.lib().wm_synth_uniform_f32(out.data_ptr(), out.numel(), int(seed),
+                                                   int(offset), float(lo), float(hi), _stream()))
+    return out
+
+
+def synth_regression(n, F, P, seed, beta, intercept=0.5, noise=0.01, dist="uniform",
+                     row_offset=0, device="cuda"):
+    beta = _req(beta.to(device), "beta")
+    X = torch.empty((n, F), device=device, dtype=torch.float32)
+    Y = torch.empty((n, P), device=device, dtype=torch.float32)
+    with torch.cuda.device(X.device):
+        _lib.check(_lib.lib().wm_synth_regression_f32(
+            X.data_ptr(), Y.data_ptr(), n, F, P, int(seed), int(row_offset), beta.data_ptr(),
+            float(intercept), float(noise), 0 if dist == "uniform" else 1, _stream()))
+    return X, Y
