@@ -48,6 +48,9 @@ def lib() -> ctypes.CDLL:
             raise ImportError(
                 f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  weather_model_amd has no CPU fallback.")
+        # torch first: libwm.so needs libamdhip64.so.7 and must bind to the HIP runtime PyTorch
+        # ships and initialises -- a second runtime loaded ahead of torch sees no device.
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)     # AttributeError if the library does not export it
