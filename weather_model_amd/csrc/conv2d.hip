@@ -22,60 +22,139 @@ namespace {
 constexpr int BLOCK = 256;
 
 // ------------------------------------------------------------------------------------------
-// row segment loader: EXT = 4 + KW - 1 floats starting at column j0 of a W-wide row.
+// Stencil kernels (Cin = Cout = 1).
+//
+// The batch is ONE stream of input rows (images are contiguous, so the row after the last row of
+// image n is row 0 of image n+1).  A thread owns a 4-column strip and a contiguous range of the
+// N*OH output rows; it loads every input row that range needs exactly once, in order, and keeps
+// the last KH rows in a register window.  Output row (n, h-KH+1) is produced at the step that
+// loads input row (n, h), for h >= hmin.  Rows are taken RB at a time: the loads of all RB rows
+// are issued back to back (a sched_barrier keeps hipcc from sinking them to their uses), so
+// RB x 24-40 B per thread are in flight while the previous rows are consumed.
+//
+// Every load is unconditional and in bounds, so hipcc never drains vmcnt at a control-flow join
+// (a bounds branch around a load costs a full memory latency per row): the last strip is shifted
+// left to start at column OW-4 instead of being masked, so a strip always reads columns
+// j0 .. j0+3+KW-1 <= W-1 and writes columns j0 .. j0+3 <= OW-1; the columns it shares with its
+// neighbour are written twice with identical values (forward) or masked out of the sums by a
+// select (backward).  All per-thread index arithmetic is 32-bit; only row pointers are 64-bit.
+#ifndef WM_STENCIL_RB
+#define WM_STENCIL_RB 4
+#endif
+#ifndef WM_STENCIL_BPC
+#define WM_STENCIL_BPC 6
+#endif
+constexpr int RB = WM_STENCIL_RB;
+
+struct RowWalk {
+    int steps;           // input rows this thread streams
+    int h;               // row-in-image of the first input row
+    int j0;              // first column of the strip
+    int qmin;            // strip columns below qmin belong to the left neighbour
+    size_t in_off;       // element offset of the first input row, at column j0
+    size_t out_off;      // element offset of the first output row, at column j0
+};
+
+// thread -> (strip, contiguous range of output rows).  rows_base/rows_rem: the N*OH rows split
+// into `segs` ranges of rows_base rows, the first rows_rem of them one row longer.
+__device__ __forceinline__ bool make_walk(RowWalk &k, int H, int W, int OH, int OW, int KH,
+                                          int strips, int segs, unsigned rows_base,
+                                          unsigned rows_rem)
+{
+    const unsigned tid = blockIdx.x * BLOCK + threadIdx.x;
+    if (tid >= (unsigned)strips * (unsigned)segs) return false;
+    const unsigned seg = tid / (unsigned)strips;
+    const unsigned strip = tid - seg * (unsigned)strips;
+    const unsigned r0 = seg * rows_base + min(seg, rows_rem);
+    const unsigned cnt = rows_base + (seg < rows_rem ? 1u : 0u);
+    if (cnt == 0) return false;
+    const unsigned n0 = r0 / (unsigned)OH, i0 = r0 - n0 * (unsigned)OH;
+    const unsigned rl = r0 + cnt - 1;
+    const unsigned n1 = rl / (unsigned)OH, i1 = rl - n1 * (unsigned)OH;
+    k.steps = (int)((n1 - n0) * (unsigned)H + i1 + KH - i0);
+    k.h = (int)i0;
+    k.j0 = min((int)strip * 4, OW - 4);
+    k.qmin = (int)strip * 4 - k.j0;
+    k.in_off = ((size_t)n0 * H + i0) * W + k.j0;
+    k.out_off = (size_t)r0 * OW + k.j0;
+    return true;
+}
+
+// EXT = 4 + KW - 1 floats starting at p (always in bounds, 4-byte aligned).
 template <int KW>
-__device__ __forceinline__ void load_row(float (&dst)[4 + KW - 1], const float *__restrict__ p,
-                                         int j0, int W)
+__device__ __forceinline__ void load_row(float (&dst)[4 + KW - 1], const float *__restrict__ p)
 {
     constexpr int EXT = 4 + KW - 1;
-    if (j0 + EXT <= W) {
-        const f4u v = *reinterpret_cast<const f4u *>(p);
-        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
-        if constexpr (KW - 1 == 2) {
-            const f2u u = *reinterpret_cast<const f2u *>(p + 4);
-            dst[4] = u.x; dst[5] = u.y;
-        } else if constexpr (KW - 1 == 4) {
-            const f4u u = *reinterpret_cast<const f4u *>(p + 4);
-            dst[4] = u.x; dst[5] = u.y; dst[6] = u.z; dst[7] = u.w;
-        } else {
-#pragma unroll
-            for (int e = 4; e < EXT; ++e) dst[e] = p[e];
-        }
+    const f4u v = *reinterpret_cast<const f4u *>(p);
+    dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+    if constexpr (KW - 1 == 2) {
+#ifdef WM_EXP_NOF2
+        dst[4] = v.x; dst[5] = v.y;
+#else
+        const f2u u = *reinterpret_cast<const f2u *>(p + 4);
+        dst[4] = u.x; dst[5] = u.y;
+#endif
+    } else if constexpr (KW - 1 == 4) {
+        const f4u u = *reinterpret_cast<const f4u *>(p + 4);
+        dst[4] = u.x; dst[5] = u.y; dst[6] = u.z; dst[7] = u.w;
     } else {
 #pragma unroll
-        for (int e = 0; e < EXT; ++e) dst[e] = (j0 + e < W) ? p[e] : 0.0f;
+        for (int e = 4; e < EXT; ++e) dst[e] = p[e];
     }
 }
 
-__device__ __forceinline__ void load4_masked(float (&dst)[4], const float *__restrict__ p, int j0,
-                                             int OW)
+template <int KH, int KW, int NB>
+__device__ __forceinline__ void fwd_batch(const float *__restrict__ &xq, float *__restrict__ &yq,
+                                          float (&win)[KH][4 + KW - 1], const float (&wr)[KH][KW],
+                                          float bias, int relu, int &h, int &hmin, int H, int W,
+                                          int OW)
 {
-    if (j0 + 4 <= OW) {
-        const f4u v = *reinterpret_cast<const f4u *>(p);
-        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
-    } else {
+    constexpr int EXT = 4 + KW - 1;
+    float rows[NB][EXT];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) dst[e] = (j0 + e < OW) ? p[e] : 0.0f;
+    for (int u = 0; u < NB; ++u) load_row<KW>(rows[u], xq + (size_t)u * W);
+    xq += (size_t)NB * W;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+#pragma unroll
+        for (int kh = 0; kh < KH - 1; ++kh)
+#pragma unroll
+            for (int e = 0; e < EXT; ++e) win[kh][e] = win[kh + 1][e];
+#pragma unroll
+        for (int e = 0; e < EXT; ++e) win[KH - 1][e] = rows[u][e];
+        if (h >= hmin) {
+            float out[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float acc = bias;
+#pragma unroll
+                for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < KW; ++kw) acc = fmaf(wr[kh][kw], win[kh][q + kw], acc);
+                out[q] = relu ? fmaxf(acc, 0.0f) : acc;
+            }
+            f4u v;
+            v.x = out[0]; v.y = out[1]; v.z = out[2]; v.w = out[3];
+            *reinterpret_cast<f4u *>(yq) = v;
+            yq += OW;
+        }
+        const bool wrap = (h + 1 == H);
+        h = wrap ? 0 : h + 1;
+        hmin = wrap ? KH - 1 : hmin;
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// stencil forward, Cin = Cout = 1.
+// stencil forward.
 template <int KH, int KW>
 __global__ __launch_bounds__(BLOCK) void conv_fwd_c1_kernel(
     const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ b,
-    float *__restrict__ y, int H, int W, int OH, int OW, int strips, long long total_rows,
-    int segs, int relu)
+    float *__restrict__ y, int H, int W, int OH, int OW, int strips, int segs,
+    unsigned rows_base, unsigned rows_rem, int relu)
 {
     constexpr int EXT = 4 + KW - 1;
-    const long long tid = (long long)blockIdx.x * BLOCK + threadIdx.x;
-    if (tid >= (long long)strips * segs) return;
-    const int strip = (int)(tid % strips);
-    const int seg = (int)(tid / strips);
-    const long long r0 = total_rows * seg / segs;
-    const long long r1 = total_rows * (seg + 1) / segs;
-    if (r0 >= r1) return;
-    const int j0 = strip * 4;
+    RowWalk wk;
+    if (!make_walk(wk, H, W, OH, OW, KH, strips, segs, rows_base, rows_rem)) return;
 
     float wr[KH][KW];
 #pragma unroll
@@ -84,72 +163,84 @@ __global__ __launch_bounds__(BLOCK) void conv_fwd_c1_kernel(
         for (int kw = 0; kw < KW; ++kw) wr[kh][kw] = w[kh * KW + kw];
     const float bias = b ? b[0] : 0.0f;
 
-    int n = (int)(r0 / OH);
-    int i = (int)(r0 - (long long)n * OH);
-    const float *xrow = x + ((size_t)n * H + i) * W + j0;   // input row i of image n, column j0
-    float *yrow = y + ((size_t)n * OH + i) * OW + j0;
+    const float *__restrict__ xq = x + wk.in_off;
+    float *__restrict__ yq = y + wk.out_off;
+    int h = wk.h, hmin = wk.h + KH - 1;
 
     float win[KH][EXT];
-    float pre[EXT];
 #pragma unroll
-    for (int kh = 0; kh < KH - 1; ++kh) load_row<KW>(win[kh], xrow + (size_t)kh * W, j0, W);
-    load_row<KW>(pre, xrow + (size_t)(KH - 1) * W, j0, W);
+    for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+        for (int e = 0; e < EXT; ++e) win[kh][e] = 0.0f;
 
-    for (long long r = r0; r < r1; ++r) {
-#pragma unroll
-        for (int e = 0; e < EXT; ++e) win[KH - 1][e] = pre[e];
-        const bool last_of_image = (i + 1 == OH);
-        // prefetch the next input row (next output row of the same image)
-        if (r + 1 < r1 && !last_of_image) load_row<KW>(pre, xrow + (size_t)KH * W, j0, W);
+    int s = 0;
+    for (; s + RB <= wk.steps; s += RB)
+        fwd_batch<KH, KW, RB>(xq, yq, win, wr, bias, relu, h, hmin, H, W, OW);
+    for (; s < wk.steps; ++s)
+        fwd_batch<KH, KW, 1>(xq, yq, win, wr, bias, relu, h, hmin, H, W, OW);
+}
 
-        float out[4];
+template <int KH, int KW, int NB>
+__device__ __forceinline__ void bwd_batch(const float *__restrict__ &xq,
+                                          const float *__restrict__ &gq,
+                                          float (&win)[KH][4 + KW - 1], float (&acc)[KH][KW],
+                                          float &accb, int qmin, int &h, int &hmin, int H, int W,
+                                          int OW)
+{
+    constexpr int EXT = 4 + KW - 1;
+    float rows[NB][EXT];
+    f4u gv[NB];
+    bool prod[NB];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float s = bias;
+    for (int u = 0; u < NB; ++u) {
+        load_row<KW>(rows[u], xq + (size_t)u * W);
+        // the gy row of a non-producing step (window refill at an image start) is loaded and
+        // ignored: gq then still points at the next row this thread consumes, always in bounds
+#ifdef WM_EXP_GALIGN
+        gv[u] = *reinterpret_cast<const f4u *>((const float *)((uintptr_t)gq & ~(uintptr_t)15));
+#else
+        gv[u] = *reinterpret_cast<const f4u *>(gq);
+#endif
+        prod[u] = h >= hmin;
+        gq += prod[u] ? OW : 0;
+        const bool wrap = (h + 1 == H);
+        h = wrap ? 0 : h + 1;
+        hmin = wrap ? KH - 1 : hmin;
+    }
+    xq += (size_t)NB * W;
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int kh = 0; kh < KH; ++kh)
-#pragma unroll
-                for (int kw = 0; kw < KW; ++kw) s = fmaf(wr[kh][kw], win[kh][q + kw], s);
-            out[q] = relu ? fmaxf(s, 0.0f) : s;
-        }
-        if (j0 + 4 <= OW) {
-            f4u v;
-            v.x = out[0]; v.y = out[1]; v.z = out[2]; v.w = out[3];
-            *reinterpret_cast<f4u *>(yrow) = v;
-        } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (j0 + q < OW) yrow[q] = out[q];
-        }
+    for (int u = 0; u < NB; ++u) {
 #pragma unroll
         for (int kh = 0; kh < KH - 1; ++kh)
 #pragma unroll
             for (int e = 0; e < EXT; ++e) win[kh][e] = win[kh + 1][e];
-
-        yrow += OW;          // output rows of consecutive images are contiguous
-        if (!last_of_image) {
-            ++i;
-            xrow += W;
-        } else {
-            i = 0;
-            ++n;
-            xrow = x + (size_t)n * H * W + j0;
-            if (r + 1 < r1) {
 #pragma unroll
-                for (int kh = 0; kh < KH - 1; ++kh)
-                    load_row<KW>(win[kh], xrow + (size_t)kh * W, j0, W);
-                load_row<KW>(pre, xrow + (size_t)(KH - 1) * W, j0, W);
-            }
-        }
+        for (int e = 0; e < EXT; ++e) win[KH - 1][e] = rows[u][e];
+        float g[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) g[q] = (prod[u] && q >= qmin) ? g[q] : 0.0f;
+#ifdef WM_EXP_NOFMA
+        accb += (g[0] + g[1]) + (g[2] + g[3]) + win[KH - 1][0] + win[KH - 1][EXT - 1];
+#else
+#pragma unroll
+        for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < KW; ++kw)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    acc[kh][kw] = fmaf(g[q], win[kh][q + kw], acc[kh][kw]);
+        accb += (g[0] + g[1]) + (g[2] + g[3]);
+#endif
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// stencil backward weight+bias, Cin = Cout = 1.  partial: [gridDim.x][KH*KW+1] float64.
+// stencil backward weight+bias.  partial: [gridDim.x][KH*KW+1] float64.
 template <int KH, int KW>
 __global__ __launch_bounds__(BLOCK) void conv_bwd_wb_c1_kernel(
     const float *__restrict__ x, const float *__restrict__ gy, double *__restrict__ partial,
-    int H, int W, int OH, int OW, int strips, long long total_rows, int segs)
+    int H, int W, int OH, int OW, int strips, int segs, unsigned rows_base, unsigned rows_rem)
 {
     constexpr int EXT = 4 + KW - 1;
     constexpr int NV = KH * KW + 1;
@@ -162,70 +253,21 @@ __global__ __launch_bounds__(BLOCK) void conv_bwd_wb_c1_kernel(
 #pragma unroll
         for (int kw = 0; kw < KW; ++kw) acc[kh][kw] = 0.0f;
 
-    const long long tid = (long long)blockIdx.x * BLOCK + threadIdx.x;
-    long long r0 = 0, r1 = 0;
-    int strip = 0;
-    if (tid < (long long)strips * segs) {
-        strip = (int)(tid % strips);
-        const int seg = (int)(tid / strips);
-        r0 = total_rows * seg / segs;
-        r1 = total_rows * (seg + 1) / segs;
-    }
-    if (r0 < r1) {
-        const int j0 = strip * 4;
-        int n = (int)(r0 / OH);
-        int i = (int)(r0 - (long long)n * OH);
-        const float *xrow = x + ((size_t)n * H + i) * W + j0;
-        const float *grow = gy + ((size_t)n * OH + i) * OW + j0;
-
+    RowWalk wk;
+    if (make_walk(wk, H, W, OH, OW, KH, strips, segs, rows_base, rows_rem)) {
+        const float *__restrict__ xq = x + wk.in_off;
+        const float *__restrict__ gq = gy + wk.out_off;
+        int h = wk.h, hmin = wk.h + KH - 1;
         float win[KH][EXT];
-        float pre[EXT];
-        float gpre[4];
 #pragma unroll
-        for (int kh = 0; kh < KH - 1; ++kh) load_row<KW>(win[kh], xrow + (size_t)kh * W, j0, W);
-        load_row<KW>(pre, xrow + (size_t)(KH - 1) * W, j0, W);
-        load4_masked(gpre, grow, j0, OW);
-
-        for (long long r = r0; r < r1; ++r) {
-            float g[4];
+        for (int kh = 0; kh < KH; ++kh)
 #pragma unroll
-            for (int e = 0; e < EXT; ++e) win[KH - 1][e] = pre[e];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) g[q] = gpre[q];
-            const bool last_of_image = (i + 1 == OH);
-            if (r + 1 < r1) {
-                load4_masked(gpre, grow + OW, j0, OW);
-                if (!last_of_image) load_row<KW>(pre, xrow + (size_t)KH * W, j0, W);
-            }
-#pragma unroll
-            for (int kh = 0; kh < KH; ++kh)
-#pragma unroll
-                for (int kw = 0; kw < KW; ++kw)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        acc[kh][kw] = fmaf(g[q], win[kh][q + kw], acc[kh][kw]);
-            accb += (g[0] + g[1]) + (g[2] + g[3]);
-#pragma unroll
-            for (int kh = 0; kh < KH - 1; ++kh)
-#pragma unroll
-                for (int e = 0; e < EXT; ++e) win[kh][e] = win[kh + 1][e];
-
-            grow += OW;
-            if (!last_of_image) {
-                ++i;
-                xrow += W;
-            } else {
-                i = 0;
-                ++n;
-                xrow = x + (size_t)n * H * W + j0;
-                if (r + 1 < r1) {
-#pragma unroll
-                    for (int kh = 0; kh < KH - 1; ++kh)
-                        load_row<KW>(win[kh], xrow + (size_t)kh * W, j0, W);
-                    load_row<KW>(pre, xrow + (size_t)(KH - 1) * W, j0, W);
-                }
-            }
-        }
+            for (int e = 0; e < EXT; ++e) win[kh][e] = 0.0f;
+        int s = 0;
+        for (; s + RB <= wk.steps; s += RB)
+            bwd_batch<KH, KW, RB>(xq, gq, win, acc, accb, wk.qmin, h, hmin, H, W, OW);
+        for (; s < wk.steps; ++s)
+            bwd_batch<KH, KW, 1>(xq, gq, win, acc, accb, wk.qmin, h, hmin, H, W, OW);
     }
     // wavefront-shuffle reduction, then LDS across the block's 4 waves, float64 partial out.
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -392,7 +434,7 @@ __global__ __launch_bounds__(BLOCK) void conv_bwd_wb_generic_kernel(
 // ------------------------------------------------------------------------------------------
 struct StencilPlan {
     int strips, segs, blocks;
-    long long total_rows;
+    unsigned rows_base, rows_rem;
 };
 
 // Cut the N*OH output rows of every 4-column strip into `segs` contiguous ranges so that
@@ -404,25 +446,29 @@ int stencil_plan(K kernel, int N, int OH, int OW, StencilPlan *p)
     WM_REQUIRE(cus > 0, WM_ERR_NO_DEVICE, "no HIP device");
     int occ = 0;
     WM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, BLOCK, 0));
-    // the occupancy query can over-report by one block per CU (MI355X_MICROARCH, residency);
-    // a launch that is not fully resident doubles the kernel time, so stay one below it.
-    int bpc = occ - 1;
-    if (bpc > 6) bpc = 6;
+    // The occupancy query over-reports only at the 8-blocks-per-CU end (SGPR-heavy kernels,
+    // MI355X_MICROARCH residency note); a launch that is not fully resident would double the
+    // kernel time, so never plan for more than 6 blocks per CU.
+    int bpc = occ;
+    if (bpc > WM_STENCIL_BPC) bpc = WM_STENCIL_BPC;
     if (bpc < 1) bpc = 1;
     p->strips = (OW + 3) / 4;
-    p->total_rows = (long long)N * OH;
+    const long long total_rows = (long long)N * OH;
     long long segs = (long long)cus * bpc * BLOCK / p->strips;
-    const long long max_segs = (p->total_rows + 7) / 8;   // at least ~8 rows per range
+    const long long max_segs = (total_rows + 7) / 8;   // at least ~8 rows per range
     if (segs > max_segs) segs = max_segs;
     if (segs < 1) segs = 1;
     p->segs = (int)segs;
+    p->rows_base = (unsigned)(total_rows / segs);
+    p->rows_rem = (unsigned)(total_rows % segs);
     p->blocks = (int)(((long long)p->strips * segs + BLOCK - 1) / BLOCK);
     return WM_OK;
 }
 
-bool stencil_shape(int Cin, int Cout, int kH, int kW, int OW)
+bool stencil_shape(int Cin, int Cout, int kH, int kW, int OW, long long total_rows)
 {
-    if (Cin != 1 || Cout != 1 || OW < 16) return false;
+    // 32-bit row arithmetic inside the kernels: N*H rows and strips*segs threads below 2^31
+    if (Cin != 1 || Cout != 1 || OW < 16 || total_rows >= (1ll << 30)) return false;
     return (kH == 3 && kW == 3) || (kH == 5 && kW == 5) || (kH == 3 && kW == 1) ||
            (kH == 1 && kW == 3) || (kH == 2 && kW == 1) || (kH == 1 && kW == 2) ||
            (kH == 2 && kW == 2) || (kH == 1 && kW == 1);
@@ -480,12 +526,12 @@ extern "C" int wm_conv2d_fwd_f32(const float *x, const float *w, const float *b,
     if (int rc = check_dims(N, Cin, H, W, Cout, kH, kW)) return rc;
     hipStream_t st = (hipStream_t)stream;
     const int OH = H - kH + 1, OW = W - kW + 1;
-    if (stencil_shape(Cin, Cout, kH, kW, OW)) {
+    if (stencil_shape(Cin, Cout, kH, kW, OW, (long long)N * H)) {
 #define FWD(KH_, KW_)                                                                       \
     StencilPlan p;                                                                          \
     if (int rc = stencil_plan(conv_fwd_c1_kernel<KH_, KW_>, N, OH, OW, &p)) return rc;      \
     hipLaunchKernelGGL((conv_fwd_c1_kernel<KH_, KW_>), dim3(p.blocks), dim3(BLOCK), 0, st, x, \
-                       w, b, y, H, W, OH, OW, p.strips, p.total_rows, p.segs, relu);
+                       w, b, y, H, W, OH, OW, p.strips, p.segs, p.rows_base, p.rows_rem, relu);
         WM_STENCIL_DISPATCH(FWD)
 #undef FWD
         WM_LAUNCH_CHECK("conv_fwd_c1_kernel");
@@ -521,7 +567,7 @@ extern "C" size_t wm_conv2d_bwd_wb_workspace_bytes(int N, int Cin, int H, int W,
         return 0;
     const int OH = H - kH + 1, OW = W - kW + 1;
     const int nw = Cout * Cin * kH * kW, nent = nw + Cout;
-    if (stencil_shape(Cin, Cout, kH, kW, OW)) {
+    if (stencil_shape(Cin, Cout, kH, kW, OW, (long long)N * H)) {
         // upper bound on the stencil grid: 6 blocks per CU (stencil_plan) + 1
         const size_t blocks = (size_t)wm_num_cus() * 6 + 1;
         return wm_align_up(blocks * (size_t)nent * sizeof(double), 256);
@@ -545,14 +591,15 @@ extern "C" int wm_conv2d_bwd_wb_f32(const float *x, const float *gy, float *gw, 
     const int nw = Cout * Cin * kH * kW, nent = nw + Cout;
     double *partial = (double *)workspace;
     int nparts = 0;
-    if (stencil_shape(Cin, Cout, kH, kW, OW)) {
+    if (stencil_shape(Cin, Cout, kH, kW, OW, (long long)N * H)) {
 #define BWD(KH_, KW_)                                                                         \
     StencilPlan p;                                                                            \
     if (int rc = stencil_plan(conv_bwd_wb_c1_kernel<KH_, KW_>, N, OH, OW, &p)) return rc;     \
     WM_REQUIRE((size_t)p.blocks * nent * sizeof(double) <= workspace_bytes, WM_ERR_WORKSPACE, \
                "wm_conv2d_bwd_wb_f32: workspace too small for %d blocks", p.blocks);          \
     hipLaunchKernelGGL((conv_bwd_wb_c1_kernel<KH_, KW_>), dim3(p.blocks), dim3(BLOCK), 0, st, \
-                       x, gy, partial, H, W, OH, OW, p.strips, p.total_rows, p.segs);         \
+                       x, gy, partial, H, W, OH, OW, p.strips, p.segs, p.rows_base,      \
+                       p.rows_rem);         \
     nparts = p.blocks;
         WM_STENCIL_DISPATCH(BWD)
 #undef BWD
