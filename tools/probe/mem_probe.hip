@@ -13,6 +13,25 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void flat_copy(const f4* __restrict__ in, f4* __restrict__ out, long long n4) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) out[i] = in[i];
 }
+__global__ __launch_bounds__(256) void flat_copy_nt(const f4* __restrict__ in, f4* __restrict__ out, long long n4, int ntload) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        f4 v = ntload ? __builtin_nontemporal_load(&in[i]) : in[i];
+        __builtin_nontemporal_store(v, &out[i]);
+    }
+}
+// chunked copy: each wave copies a contiguous range, 4 KiB per iteration
+__global__ __launch_bounds__(256) void chunk_copy(const f4* __restrict__ in, f4* __restrict__ out, long long n4, int nt) {
+    const long long nw = (long long)gridDim.x * 4, w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long t0 = (n4 / 64) * w / nw, t1 = (n4 / 64) * (w + 1) / nw;
+    const int lane = threadIdx.x & 63;
+    for (long long t = t0; t + 4 <= t1; t += 4) {
+        f4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = in[(t + u) * 64 + lane];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { if (nt) __builtin_nontemporal_store(v[u], &out[(t + u) * 64 + lane]); else out[(t + u) * 64 + lane] = v[u]; }
+    }
+}
 __global__ __launch_bounds__(256) void flat_read(const f4* __restrict__ in, float* __restrict__ out, long long n4) {
     f4 s = {0, 0, 0, 0};
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) s += in[i];
@@ -71,12 +90,39 @@ __global__ __launch_bounds__(256) void row_walk(const float* __restrict__ x, con
                 }
                 v.x += v2.x; v.y += v2.y;
                 if (MODE & 4) v += gv;
-                if (MODE & 2) { if (ofull) *(f4u*)(yp + (size_t)(s + u) * OW) = v; }
+                if (MODE & 2) { if (ofull) { if (MODE & 8) __builtin_nontemporal_store(v, (f4u*)(yp + (size_t)(s + u) * OW)); else *(f4u*)(yp + (size_t)(s + u) * OW) = v; } }
                 else acc += v;
             }
         }
     }
     if (!(MODE & 2) && acc.x + acc.y + acc.z + acc.w == 12345.678f) y[0] = acc.x;
+}
+
+// band sweep: item = (band of R output rows, 4-column strip), items taken grid-stride in band-major
+// order so the blocks in flight cover a compact window of rows.  Loads R+2 rows (f4+f2), stores R.
+template <int R, int NT>
+__global__ __launch_bounds__(256) void band_copy(const float* __restrict__ x, float* __restrict__ y, int W, int OW, int strips, int total_rows) {
+    const int bands = (total_rows + R - 1) / R;
+    const long long items = (long long)bands * strips;
+    for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < items; it += (long long)gridDim.x * 256) {
+        const int band = it / strips, strip = it - (long long)band * strips;
+        const int j0 = min(strip * 4, OW - 4);
+        const int r0 = band * R;
+        const int cnt = min(R, total_rows - r0 - 2);
+        if (cnt <= 0) continue;
+        const float* xp = x + (size_t)r0 * W + j0;
+        float* yp = y + (size_t)r0 * OW + j0;
+        f4u v[R + 2]; f2u v2[R + 2];
+#pragma unroll
+        for (int u = 0; u < R + 2; ++u) { const int uu = min(u, cnt + 1); v[u] = *(const f4u*)(xp + (size_t)uu * W); v2[u] = *(const f2u*)(xp + (size_t)uu * W + 4); }
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            if (u < cnt) {
+                f4u o = v[u] + v[u + 1] + v[u + 2]; o.x += v2[u].x + v2[u + 1].y + v2[u + 2].x;
+                if (NT) __builtin_nontemporal_store(o, (f4u*)(yp + (size_t)u * OW)); else *(f4u*)(yp + (size_t)u * OW) = o;
+            }
+        }
+    }
 }
 
 template <typename F>
@@ -109,6 +155,18 @@ int main(int argc, char** argv) {
         ms = time_ms([&](int r) { hipLaunchKernelGGL(flat_read, dim3(grid), dim3(256), 0, 0, (const f4*)x[r % NB], y[0], n / 4); }, reps);
         printf("flat_read   grid %5d: %.1f us  %.0f GB/s\n", grid, ms * 1e3, MB / ms);
     }
+    for (int grid : {256, 512, 768, 1024, 1536, 2048}) {
+        float ms = time_ms([&](int r) { hipLaunchKernelGGL(flat_copy, dim3(grid), dim3(256), 0, 0, (const f4*)x[r % NB], (f4*)y[r % NB], n / 4); }, reps);
+        printf("flat_copy      grid %5d: %.1f us  %.0f GB/s (r+w)\n", grid, ms * 1e3, 2 * MB / ms);
+        ms = time_ms([&](int r) { hipLaunchKernelGGL(flat_copy_nt, dim3(grid), dim3(256), 0, 0, (const f4*)x[r % NB], (f4*)y[r % NB], n / 4, 0); }, reps);
+        printf("flat_copy_nt   grid %5d: %.1f us  %.0f GB/s (r+w)\n", grid, ms * 1e3, 2 * MB / ms);
+        ms = time_ms([&](int r) { hipLaunchKernelGGL(flat_copy_nt, dim3(grid), dim3(256), 0, 0, (const f4*)x[r % NB], (f4*)y[r % NB], n / 4, 1); }, reps);
+        printf("flat_copy_ntnt grid %5d: %.1f us  %.0f GB/s (r+w)\n", grid, ms * 1e3, 2 * MB / ms);
+        ms = time_ms([&](int r) { hipLaunchKernelGGL(chunk_copy, dim3(grid), dim3(256), 0, 0, (const f4*)x[r % NB], (f4*)y[r % NB], n / 4, 0); }, reps);
+        printf("chunk_copy     grid %5d: %.1f us  %.0f GB/s (r+w)\n", grid, ms * 1e3, 2 * MB / ms);
+        ms = time_ms([&](int r) { hipLaunchKernelGGL(chunk_copy, dim3(grid), dim3(256), 0, 0, (const f4*)x[r % NB], (f4*)y[r % NB], n / 4, 1); }, reps);
+        printf("chunk_copy_nt  grid %5d: %.1f us  %.0f GB/s (r+w)\n", grid, ms * 1e3, 2 * MB / ms);
+    }
     for (int grid : {512, 1024, 2048}) {
         float ms = time_ms([&](int r) { hipLaunchKernelGGL(chunk_read, dim3(grid), dim3(256), 0, 0, (const f4*)x[r % NB], y[0], n / 4); }, reps);
         printf("chunk_read  grid %5d: %.1f us  %.0f GB/s\n", grid, ms * 1e3, MB / ms);
@@ -119,20 +177,16 @@ int main(int argc, char** argv) {
         const int segs = 256 * bpc * 256 / strips; const int blocks = (strips * segs + 255) / 256; \
         float ms = time_ms([&](int r) { hipLaunchKernelGGL((row_walk<MODE, PFD>), dim3(blocks), dim3(256), 0, 0, x[r % NB], g[r % NB], y[r % NB], W, OW, strips, rows, segs); }, reps); \
         printf("row_walk %-28s pf %d bpc %d: %.1f us  %.0f GB/s\n", label, PFD, bpc, ms * 1e3, (bytes_mb) / ms); }
-    for (int bpc : {2, 4, 6, 8}) {
-        RW(0, 4, bpc, "read x", MB)
-        RW(1, 4, bpc, "read x + f2", MB)
-        RW(4, 4, bpc, "read x + g(1438)", 2 * MB)
-        RW(5, 4, bpc, "read x + f2 + g(1438)", 2 * MB)
-        RW(2, 4, bpc, "copy x -> y(1438)", 2 * MB)
-        RW(3, 4, bpc, "copy x + f2 -> y(1438)", 2 * MB)
+#define BC(R, NT, grid, ow) { float ms = time_ms([&](int r) { hipLaunchKernelGGL((band_copy<R, NT>), dim3(grid), dim3(256), 0, 0, x[r % NB], y[r % NB], W, ow, strips, (int)rows); }, reps); \
+        printf("band_copy R %2d nt %d grid %5d ow %d: %.1f us  %.0f GB/s\n", R, NT, grid, ow, ms * 1e3, 2 * MB / ms); }
+    for (int grid : {768, 1024, 2048}) {
+        BC(6, 0, grid, 1438) BC(6, 0, grid, 1440) BC(6, 0, grid, 1436) BC(6, 1, grid, 1440) BC(14, 0, grid, 1440) BC(14, 1, grid, 1440)
     }
-    for (int bpc : {4, 6}) {
+    for (int bpc : {4}) {
         RW(3, 1, bpc, "copy x + f2 -> y(1438)", 2 * MB)
-        RW(3, 2, bpc, "copy x + f2 -> y(1438)", 2 * MB)
-        RW(3, 8, bpc, "copy x + f2 -> y(1438)", 2 * MB)
-        RW(5, 1, bpc, "read x + f2 + g(1438)", 2 * MB)
-        RW(5, 8, bpc, "read x + f2 + g(1438)", 2 * MB)
+        RW(3, 4, bpc, "copy x + f2 -> y(1438)", 2 * MB)
+        RW(11, 1, bpc, "copy x + f2 -> y(1438) nt", 2 * MB)
+        RW(11, 4, bpc, "copy x + f2 -> y(1438) nt", 2 * MB)
     }
     return 0;
 }
