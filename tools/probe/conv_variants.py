@@ -7,9 +7,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 VDIR = os.path.join(HERE, "variants")
 CSRC = os.path.join(ROOT, "weather_model_amd", "csrc")
-RBS = [1, 2, 4]
-BPCS = [4, 6]
-EXPS = ["", "-DWM_EXP_NOFMA"]
+RBS = [2, 4]
+BPCS = [3, 4, 6]
+EXPS = ["", "-DWM_EXP_NTSTORE"]
 
 def build():
     os.makedirs(VDIR, exist_ok=True)
