@@ -99,6 +99,35 @@ int wm_normal_solve_f64(const double *acc, int F, int P, int fit_intercept, doub
 int wm_linear_predict_f32(const float *X, const double *beta, float *Yhat,
                           int64_t n, int F, int P, void *stream);
 
+/* ------------------------------------------------------------------ fused model --------- */
+
+/* The reference's conv interpolation model (newConvolution.py:109-163), batched over B grid points.
+ * params: the 20566 forward-path parameters, flat, in PyTorch parameter order
+ *   conv1.weight(16,1,2,1) conv1.bias conv2.weight(32,16,3,1) conv2.bias conv3.weight(32,32,3,1)
+ *   conv3.bias conv4.weight conv4.bias linear1.weight(64,192) linear1.bias linear2.weight(6,64)
+ *   linear2.bias                                     (newConvolution.py:129-136)
+ * x: B x 2 x 6 (rows: start, end; newConvolution.py:100-104); out: B x 6.
+ * wm_model_fwd_f32 replaces CustomModel.forward (newConvolution.py:146-163) for every sample. */
+int    wm_model_param_count(void);
+int    wm_model_fwd_f32(const float *params, const float *x, float *out, int64_t B, void *stream);
+
+/* Forward + backward: replaces model(x) + loss_fn + loss.backward() (newConvolution.py:180-184).
+ * Pass y (B x 6) for the fused nn.MSELoss (mean over all 6*B_global outputs; *loss receives this
+ * rank's share sum_local (out-y)^2 / (6*B_global)), or dout (B x 6) = dL/dout from autograd; the
+ * other must be NULL.  grads: 20566 floats, same layout as params (overwritten, bitwise
+ * reproducible).  B_global >= B is the batch the mean runs over (data parallel: all-reduce(sum)
+ * grads afterwards). */
+size_t wm_model_workspace_bytes(int64_t B);
+int    wm_model_train_f32(const float *params, const float *x, const float *y, const float *dout,
+                          float *out, float *loss, float *grads, void *workspace,
+                          size_t workspace_bytes, int64_t B, int64_t B_global, void *stream);
+
+/* torch.optim.Adam step with the reference's defaults semantics (newConvolution.py:185,225):
+ * no weight decay, no amsgrad; step counts from 1; grads are multiplied by grad_scale first. */
+int    wm_adam_step_f32(float *params, const float *grads, float *m, float *v, int64_t count,
+                        int step, float lr, float beta1, float beta2, float eps, float grad_scale,
+                        void *stream);
+
 /* ------------------------------------------------------------------ synthetic data ------ */
 
 /* Counter-based generator: element i of `out` depends only on (seed, offset + i).  Same hash as

@@ -1,0 +1,138 @@
+"""GPU parity: fused reference-shaped model (through the C ABI) vs the reference's own outputs
+(tests/golden/model_golden.npz, produced by running newConvolution.CustomModel) and vs the numpy
+float64 oracle.  Tolerance 1e-5 relative (BASELINE.json)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import relinf
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _sd(g, prefix="sd0/"):
+    return {k[len(prefix):]: g[k] for k in g.files if k.startswith(prefix)}
+
+
+def _flat(sd):
+    from weather_model_amd import ops
+    return np.concatenate([np.asarray(sd[n], np.float32).reshape(-1) for n, _ in ops.MODEL_PARAM_SHAPES])
+
+
+def _split(flat):
+    from weather_model_amd import ops
+    out, off = {}, 0
+    for n, shp in ops.MODEL_PARAM_SHAPES:
+        k = int(np.prod(shp))
+        out[n] = flat[off:off + k].reshape(shp)
+        off += k
+    return out
+
+
+def test_forward_matches_reference_outputs(model_golden):
+    from weather_model_amd import ops
+    from oracle import model_ref
+    g = model_golden
+    p = torch.from_numpy(_flat(_sd(g))).cuda()
+    x = torch.from_numpy(g["x"][:, 0]).cuda()                      # (64,2,6)
+    out = ops.model_forward(p, x).cpu().numpy()
+    assert relinf(out, g["out"]) < TOL                              # the reference's own outputs
+    assert relinf(out, model_ref.forward(_sd(g), g["x"][:, 0])) < TOL
+    # the reference's single-sample call shape (1,2,6) gives the same row
+    one = ops.model_forward(p, x[3:4]).cpu().numpy()
+    assert np.array_equal(one[0], out[3])
+    # ragged batch sizes (tile = 16 samples)
+    for B in (1, 15, 17, 33):
+        o = ops.model_forward(p, x[:B]).cpu().numpy()
+        assert np.array_equal(o, out[:B])
+
+
+def test_gradients_match_reference(model_golden):
+    from weather_model_amd import ops
+    from oracle import model_ref
+    g = model_golden
+    sd = _sd(g)
+    p = torch.from_numpy(_flat(sd)).cuda()
+    x = torch.from_numpy(g["x"][:, 0]).cuda()
+    y = torch.from_numpy(g["y"][:, 0]).cuda()
+    # per-sample gradients the reference produced for samples 0..3
+    for i in range(4):
+        out, loss, grads = ops.model_train(p, x[i:i + 1], y=y[i:i + 1])
+        gs = _split(grads.cpu().numpy())
+        assert abs(float(loss) - g["loss"][i]) < 1e-5 * max(1.0, g["loss"][i])
+        for n in gs:
+            ref = g["grad4/" + n][i]
+            scale = max(np.abs(ref).max(), 1e-6)
+            assert np.abs(gs[n] - ref).max() / scale < 2e-5, (i, n)
+    # batch of 64 = mean of the reference's per-sample gradients
+    out, loss, grads = ops.model_train(p, x, y=y)
+    gs = _split(grads.cpu().numpy())
+    oloss, _, ograds = model_ref.loss_and_grads(sd, g["x"][:, 0], g["y"][:, 0])
+    assert abs(float(loss) - oloss) < 1e-5 * oloss
+    for n in gs:
+        assert relinf(gs[n], g["gradmean64/" + n]) < 2e-5, n
+        assert relinf(gs[n], ograds[n]) < TOL, n
+    # bitwise reproducible
+    _, _, grads2 = ops.model_train(p, x, y=y)
+    assert torch.equal(grads, grads2)
+
+
+def test_autograd_path_and_given_dout(model_golden):
+    from weather_model_amd import ops
+    g = model_golden
+    p = torch.from_numpy(_flat(_sd(g))).cuda().requires_grad_(True)
+    x = torch.from_numpy(g["x"][:20, 0]).cuda()
+    y = torch.from_numpy(g["y"][:20, 0]).cuda()
+    out = ops.ModelFunction.apply(p, x)
+    loss = torch.nn.functional.mse_loss(out, y)           # loss_fn at newConvolution.py:181
+    loss.backward()                                        # :184
+    _, loss2, grads = ops.model_train(p.detach(), x, y=y)
+    assert abs(float(loss.detach()) - float(loss2)) < 1e-6
+    assert relinf(p.grad.cpu().numpy(), grads.cpu().numpy()) < 1e-5
+
+
+def test_adam_steps_match_reference(model_golden):
+    from weather_model_amd import ops
+    g = model_golden
+    sd = _sd(g)
+    p = torch.from_numpy(_flat(sd)).cuda()
+    m = torch.zeros_like(p)
+    v = torch.zeros_like(p)
+    x = torch.from_numpy(g["x"][:, 0]).cuda()
+    y = torch.from_numpy(g["y"][:, 0]).cuda()
+    for step in range(3):
+        _, _, grads = ops.model_train(p, x[step:step + 1], y=y[step:step + 1])
+        ops.adam_step(p, grads, m, v, step + 1)
+        ref = _flat(_sd(g, f"adam{step + 1}/"))
+        assert np.abs(p.cpu().numpy() - ref).max() < 2e-5, step
+    # batched step (mean gradient over 8 samples)
+    p = torch.from_numpy(_flat(sd)).cuda()
+    m.zero_(); v.zero_()
+    _, _, grads = ops.model_train(p, x[:8], y=y[:8])
+    ops.adam_step(p, grads, m, v, 1)
+    assert np.abs(p.cpu().numpy() - _flat(_sd(g, "adam_b8/"))).max() < 2e-5
+
+
+def test_large_batch_properties():
+    """1e5 samples: per-sample outputs independent of batching; gradient of a doubled batch
+    equals the gradient of the batch (mean semantics)."""
+    from weather_model_amd import ops, synth
+    from oracle import model_ref
+    rng = {n: synth.uniform(500 + k, shp, -0.3, 0.3) for k, (n, shp) in enumerate(ops.MODEL_PARAM_SHAPES)}
+    p = torch.from_numpy(_flat(rng)).cuda()
+    B = 100_003
+    x = ops.synth_uniform((B, 2, 6), seed=77)
+    y = ops.synth_uniform((B, 6), seed=78)
+    out = ops.model_forward(p, x)
+    idx = [0, 1, 4095, 65536, B - 1]
+    ref = model_ref.forward(rng, x[idx].cpu().numpy())
+    assert relinf(out[idx].cpu().numpy(), ref) < TOL
+    _, l1, g1 = ops.model_train(p, x, y=y)
+    _, l2, g2 = ops.model_train(p, torch.cat([x, x]), y=torch.cat([y, y]))
+    assert abs(float(l1) - float(l2)) < 1e-5 * float(l1)
+    assert relinf(g2.cpu().numpy(), g1.cpu().numpy()) < 1e-5
+    ol, _, og = model_ref.loss_and_grads(rng, x[:4096].cpu().numpy(), y[:4096].cpu().numpy())
+    _, l3, g3 = ops.model_train(p, x[:4096], y=y[:4096])
+    assert abs(float(l3) - ol) < 1e-5 * ol
+    assert relinf(g3.cpu().numpy(), _flat(og)) < TOL

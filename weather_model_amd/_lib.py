@@ -24,6 +24,11 @@ SIGNATURES = {
     "wm_normal_solve_workspace_bytes": (c_sz, [c_int, c_int]),
     "wm_normal_solve_f64": (c_int, [vp, c_int, c_int, c_int, c_f64, vp, vp, vp, c_sz, vp]),
     "wm_linear_predict_f32": (c_int, [vp, vp, vp, c_i64, c_int, c_int, vp]),
+    "wm_model_param_count": (c_int, []),
+    "wm_model_fwd_f32": (c_int, [vp, vp, vp, c_i64, vp]),
+    "wm_model_workspace_bytes": (c_sz, [c_i64]),
+    "wm_model_train_f32": (c_int, [vp, vp, vp, vp, vp, vp, vp, vp, c_sz, c_i64, c_i64, vp]),
+    "wm_adam_step_f32": (c_int, [vp, vp, vp, vp, c_i64, c_int, c_f32, c_f32, c_f32, c_f32, c_f32, vp]),
     "wm_synth_uniform_f32": (c_int, [vp, c_i64, c_u64, c_u64, c_f32, c_f32, vp]),
     "wm_synth_regression_f32": (c_int, [vp, vp, c_i64, c_int, c_int, c_u64, c_u64, vp, c_f32,
                                         c_f32, c_int, vp]),

@@ -1,0 +1,550 @@
+// model.hip -- the reference's conv interpolation model, batched and fused (BASELINE config 4a).
+//
+// Replaces, for a batch of B grid points, what the reference does one grid point at a time:
+//   CustomModel.forward            newConvolution.py:146-163  (conv1..conv4 + concatenate_bounds
+//                                  :139-144 + ReLU, Flatten, linear1, tanh, linear2)
+//   loss.backward()                newConvolution.py:184      (all 12 forward-path gradients)
+//   nn.MSELoss / Adam step         newConvolution.py:181,185-186,224-225
+//
+// Algebra.  Every kernel of the conv stack has width 1, so the 6 variable columns of a sample
+// never mix before linear1, and concatenate_bounds makes every conv input [start; h_c; end] for
+// every channel c.  A (3,1) conv is therefore, per column n,
+//     z[o,n] = b[o] + (sum_c W[o,c,0]) s[n] + (sum_c W[o,c,2]) e[n] + sum_c W[o,c,1] h[c,n]
+// -- one dense (Cout x Cin) contraction plus rank-1 terms -- i.e. a chain of small GEMMs over the
+// columns.  concatenate_bounds costs nothing: it is index arithmetic.
+//
+// Kernel.  One 512-thread workgroup owns tiles of 16 samples = 96 columns (column = w*16 + s, so
+// the six columns of a sample sit 16 apart and linear1 sees one 16-column block per variable).
+// Activations of every layer live in LDS; each layer is a set of 16x16 output tiles computed with
+// v_mfma_f32_16x16x4_f32 (weights straight from global memory / L1, activations from LDS) and
+// handed to waves round-robin.  The backward pass recomputes nothing: the forward's LDS tiles are
+// still there.  Weight gradients are 74 16x16 tiles, each OWNED by one wave and accumulated in its
+// registers across all the tiles the workgroup processes; they are written once per workgroup
+// (float32 tile space) and a finalize kernel sums the workgroups in a fixed order in float64 and
+// scatters into the PyTorch parameter layout -- deterministic, no atomics.
+#include "common.h"
+
+namespace {
+
+constexpr int TS = 16;          // samples per tile
+constexpr int NC = 6 * TS;      // columns per tile
+constexpr int NP = 98;          // LDS row stride of column-indexed arrays (conflict-free transposed reads)
+constexpr int SP = 18;          // LDS row stride of sample-indexed arrays
+constexpr int THREADS = 512;
+constexpr int WAVES = THREADS / 64;
+constexpr int NTILES = 74;      // weight-gradient tiles
+constexpr int SLOTS = (NTILES + WAVES - 1) / WAVES;
+constexpr int NPARAM = 20566;
+
+// flat parameter layout = PyTorch parameter order of the forward path
+constexpr int P_C1W = 0, P_C1B = 32, P_C2W = 48, P_C2B = 1584, P_C3W = 1616, P_C3B = 4688,
+              P_C4W = 4720, P_C4B = 7792, P_L1W = 7824, P_L1B = 20112, P_L2W = 20176,
+              P_L2B = 20560;
+
+// LDS map (float offsets)
+constexpr int L_XS = 0;                      // [2][NP]   start / end rows
+constexpr int L_EE = L_XS + 2 * NP;          // [16][NP]  rows: 1, s, e, 0...
+constexpr int L_H1 = L_EE + 16 * NP;         // [16][NP]
+constexpr int L_H2 = L_H1 + 16 * NP;         // [32][NP]
+constexpr int L_H3 = L_H2 + 32 * NP;
+constexpr int L_H4 = L_H3 + 32 * NP;
+constexpr int L_Z4 = L_H4 + 32 * NP;         // dL/dz of conv4 .. conv1
+constexpr int L_Z3 = L_Z4 + 32 * NP;
+constexpr int L_Z2 = L_Z3 + 32 * NP;
+constexpr int L_Z1 = L_Z2 + 32 * NP;         // [16][NP]
+constexpr int L_UU = L_Z1 + 16 * NP;         // [2][64][SP] partial linear1 sums
+constexpr int L_TT = L_UU + 2 * 64 * SP;     // [64][SP]  tanh output
+constexpr int L_DU = L_TT + 64 * SP;         // [64][SP]
+constexpr int L_DO = L_DU + 64 * SP;         // [16][SP]  out, then dL/dout (rows >= 6 zero)
+constexpr int L_E2 = L_DO + 16 * SP;         // [16][SP]  row 0 = 1, rest 0
+constexpr int L_AUX = L_E2 + 16 * SP;        // [3 layers][2][32]  sum_c W[o,c,0], sum_c W[o,c,2]
+constexpr int L_RED = L_AUX + 192;           // [WAVES] loss partials
+constexpr int L_TOTAL = L_RED + 16;
+constexpr size_t LDS_BYTES = (size_t)L_TOTAL * sizeof(float);
+
+__device__ __forceinline__ f32x4 mma(float a, float b, f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// write a 16x16 accumulator tile (row = 4g + r, col = i) into an LDS matrix
+__device__ __forceinline__ void put_tile(float *dst, int stride, int row0, int col0, f32x4 acc,
+                                         int i, int g)
+{
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dst[(row0 + 4 * g + r) * stride + col0 + i] = acc[r];
+}
+
+// forward conv layer: Hout[o][n] = relu(b[o] + as[o] s[n] + ae[o] e[n] + sum_c Wm[o][c] Hin[c][n])
+// K = Cin (0 for conv1), O = Cout; weight element (o,c) sits at wbase[(o*K + c)*3 + 1].
+template <int K, int O>
+__device__ __forceinline__ void conv_fwd_layer(float *lds, const float *__restrict__ wmid,
+                                               const float *__restrict__ bias,
+                                               const float *as, const float *ae, int hin, int hout,
+                                               int wave, int i, int g)
+{
+    constexpr int UNITS = (O / 16) * 6;
+    for (int u = wave; u < UNITS; u += WAVES) {
+        const int o0 = (u / 6) * 16, c0 = (u % 6) * 16;
+        const int o = o0 + i;
+        // rank-1 terms and bias as one MFMA step: A = [b, as, ae, 0], B = [1, s, e, 0]
+        const float a0 = g == 0 ? bias[o] : (g == 1 ? as[o] : (g == 2 ? ae[o] : 0.0f));
+        const float b0 = lds[L_EE + g * NP + c0 + i];   // EE rows 0..3 = 1, s, e, 0
+        f32x4 acc = mma(a0, b0, (f32x4){0.f, 0.f, 0.f, 0.f});
+        if constexpr (K > 0) {
+#pragma unroll 4
+            for (int t = 0; t < K / 4; ++t) {
+                const int k = t + (K / 4) * g;
+                acc = mma(wmid[(o * K + k) * 3 + 1], lds[hin + k * NP + c0 + i], acc);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = fmaxf(acc[r], 0.0f);
+        put_tile(lds + hout, NP, o0, c0, acc, i, g);
+    }
+}
+
+// backward-data of a conv layer: dZin[c][n] = relu'(Hin[c][n]) * sum_o Wm[o][c] dZout[o][n]
+template <int K, int O>   // K = Cin (rows produced), O = Cout (contraction)
+__device__ __forceinline__ void conv_bwd_data_layer(float *lds, const float *__restrict__ wmid,
+                                                    int zout, int hin, int zin, int wave, int i,
+                                                    int g)
+{
+    constexpr int UNITS = (K / 16) * 6;
+    for (int u = wave; u < UNITS; u += WAVES) {
+        const int c0 = (u / 6) * 16, n0 = (u % 6) * 16;
+        const int c = c0 + i;
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int t = 0; t < O / 4; ++t) {
+            const int o = t + (O / 4) * g;
+            acc = mma(wmid[(o * K + c) * 3 + 1], lds[zout + o * NP + n0 + i], acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float hv = lds[hin + (c0 + 4 * g + r) * NP + n0 + i];
+            acc[r] = hv > 0.0f ? acc[r] : 0.0f;
+        }
+        put_tile(lds + zin, NP, c0, n0, acc, i, g);
+    }
+}
+
+// weight-gradient tile: C[a][b] += sum_k A[arow0 + a][ka0 + k] * B[brow0 + b][kb0 + k]
+struct GradTile {
+    int a_off, a_stride, b_off, b_stride, ka0, kb0, steps;
+};
+
+__device__ __forceinline__ GradTile grad_tile(int id)
+{
+    GradTile t;
+    t.a_stride = NP; t.b_stride = NP; t.ka0 = 0; t.kb0 = 0; t.steps = NC / 4;
+    if (id < 17) {
+        // conv layers: per layer [main tiles ..., extras ...]
+        int zoff, hoff, lid = id;
+        if (id < 6)       { zoff = L_Z4; hoff = L_H3; }
+        else if (id < 12) { zoff = L_Z3; hoff = L_H2; lid = id - 6; }
+        else if (id < 16) { zoff = L_Z2; hoff = L_H1; lid = id - 12; }
+        else              { zoff = L_Z1; hoff = L_EE; lid = 0; }
+        if (id < 12) {           // conv4 / conv3: 4 main (ot*2+ct), 2 extras (ot)
+            if (lid < 4) { t.a_off = zoff + (lid >> 1) * 16 * NP; t.b_off = hoff + (lid & 1) * 16 * NP; }
+            else         { t.a_off = zoff + (lid - 4) * 16 * NP; t.b_off = L_EE; }
+        } else if (id < 16) {    // conv2: 2 main (ot), 2 extras (ot)
+            if (lid < 2) { t.a_off = zoff + lid * 16 * NP; t.b_off = hoff; }
+            else         { t.a_off = zoff + (lid - 2) * 16 * NP; t.b_off = L_EE; }
+        } else {                 // conv1: extras only
+            t.a_off = zoff; t.b_off = L_EE;
+        }
+    } else if (id < 65) {        // linear1 main: 17 + (jt*6 + w)*2 + ct
+        const int q = id - 17, ct = q & 1, jw = q >> 1, w = jw % 6, jt = jw / 6;
+        t.a_off = L_DU + jt * 16 * SP; t.a_stride = SP; t.ka0 = 0;
+        t.b_off = L_H4 + ct * 16 * NP; t.b_stride = NP; t.kb0 = w * 16;
+        t.steps = TS / 4;
+    } else if (id < 69) {        // linear1 bias (jt)
+        t.a_off = L_DU + (id - 65) * 16 * SP; t.a_stride = SP;
+        t.b_off = L_E2; t.b_stride = SP; t.steps = TS / 4;
+    } else if (id < 73) {        // linear2 main (jt): C[m][j]
+        t.a_off = L_DO; t.a_stride = SP;
+        t.b_off = L_TT + (id - 69) * 16 * SP; t.b_stride = SP; t.steps = TS / 4;
+    } else {                     // linear2 bias
+        t.a_off = L_DO; t.a_stride = SP; t.b_off = L_E2; t.b_stride = SP; t.steps = TS / 4;
+    }
+    return t;
+}
+
+// MODE 0: forward only.  MODE 1: forward + backward with dL/dout = 2 (out - y) * dscale (fused
+// MSE).  MODE 2: forward + backward with dL/dout given.
+template <int MODE>
+__global__ __launch_bounds__(THREADS) void model_kernel(
+    const float *__restrict__ prm, const float *__restrict__ x, const float *__restrict__ y,
+    const float *__restrict__ dout, float *__restrict__ out, float *__restrict__ gtiles,
+    float *__restrict__ loss_part, long long B, float dscale)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+
+    // per-workgroup constants: rank-1 coefficients of conv2..4, the constant rows of EE / E2
+    for (int e = tid; e < 192; e += THREADS) {
+        const int layer = e / 64, which = (e >> 5) & 1, o = e & 31;
+        const int K = layer == 0 ? 16 : 32;
+        const float *w = prm + (layer == 0 ? P_C2W : (layer == 1 ? P_C3W : P_C4W));
+        float s = 0.0f;
+        for (int c = 0; c < K; ++c) s += w[(o * K + c) * 3 + (which ? 2 : 0)];
+        lds[L_AUX + e] = s;
+    }
+    for (int e = tid; e < 16 * NP; e += THREADS) lds[L_EE + e] = (e < NP) ? 1.0f : 0.0f;
+    for (int e = tid; e < 16 * SP; e += THREADS) {
+        lds[L_E2 + e] = (e < SP) ? 1.0f : 0.0f;
+        lds[L_DO + e] = 0.0f;
+    }
+    f32x4 gacc[SLOTS];
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) gacc[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float loss_acc = 0.0f;
+    __syncthreads();
+
+    const long long ntiles = (B + TS - 1) / TS;
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long s0 = tile * TS;
+        // ---- load x: XS[r][w*16+s] = x[s][r][w]; EE rows 1,2 mirror it
+        if (tid < 2 * NC) {
+            const int r = tid / NC, col = tid % NC, w = col >> 4, s = col & 15;
+            const long long smp = s0 + s;
+            const float v = smp < B ? x[smp * 12 + r * 6 + w] : 0.0f;
+            lds[L_XS + r * NP + col] = v;
+            lds[L_EE + (1 + r) * NP + col] = v;
+        }
+        __syncthreads();
+        // ---- forward
+        // conv1 weight (16,1,2,1): as = W[o][0][0], ae = W[o][0][1]  (strided view)
+        {
+            const float *w1 = prm + P_C1W;
+            constexpr int UNITS = 6;
+            for (int u = wave; u < UNITS; u += WAVES) {
+                const int c0 = u * 16, o = i;
+                const float a0 = g == 0 ? prm[P_C1B + o] : (g == 1 ? w1[o * 2] : (g == 2 ? w1[o * 2 + 1] : 0.0f));
+                const float b0 = lds[L_EE + g * NP + c0 + i];
+                f32x4 acc = mma(a0, b0, (f32x4){0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = fmaxf(acc[r], 0.0f);
+                put_tile(lds + L_H1, NP, 0, c0, acc, i, g);
+            }
+        }
+        __syncthreads();
+        conv_fwd_layer<16, 32>(lds, prm + P_C2W, prm + P_C2B, lds + L_AUX, lds + L_AUX + 32, L_H1,
+                               L_H2, wave, i, g);
+        __syncthreads();
+        conv_fwd_layer<32, 32>(lds, prm + P_C3W, prm + P_C3B, lds + L_AUX + 64, lds + L_AUX + 96,
+                               L_H2, L_H3, wave, i, g);
+        __syncthreads();
+        conv_fwd_layer<32, 32>(lds, prm + P_C4W, prm + P_C4B, lds + L_AUX + 128,
+                               lds + L_AUX + 160, L_H3, L_H4, wave, i, g);
+        __syncthreads();
+        // linear1: u[j][s] = sum_w sum_c L1[j][c*6+w] H4[c][w*16+s]; 8 units = 4 j-tiles x 2 w-halves
+        {
+            const int jt = wave >> 1, half = wave & 1;
+            const float *l1 = prm + P_L1W;
+            const int j = jt * 16 + i;
+            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int w = half * 3; w < half * 3 + 3; ++w) {
+#pragma unroll 4
+                for (int t = 0; t < 8; ++t) {
+                    const int c = t + 8 * g;
+                    acc = mma(l1[j * 192 + c * 6 + w], lds[L_H4 + c * NP + w * 16 + i], acc);
+                }
+            }
+            put_tile(lds + L_UU + half * 64 * SP, SP, jt * 16, 0, acc, i, g);
+        }
+        __syncthreads();
+        for (int e = tid; e < 64 * TS; e += THREADS) {
+            const int j = e >> 4, s = e & 15;
+            const float u = lds[L_UU + j * SP + s] + lds[L_UU + 64 * SP + j * SP + s] + prm[P_L1B + j];
+            lds[L_TT + j * SP + s] = tanhf(u);
+        }
+        __syncthreads();
+        // linear2: out[m][s] = bl2[m] + sum_j L2[m][j] T[j][s]   (one unit; rows m >= 6 are zero)
+        if (wave == 0) {
+            const float *l2 = prm + P_L2W;
+            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+            for (int t = 0; t < 16; ++t) {
+                const int j = t + 16 * g;
+                acc = mma(i < 6 ? l2[i * 64 + j] : 0.0f, lds[L_TT + j * SP + i], acc);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = 4 * g + r;
+                const long long smp = s0 + i;
+                float o = 0.0f;
+                if (m < 6) {
+                    o = acc[r] + prm[P_L2B + m];
+                    if (smp < B) out[smp * 6 + m] = o;
+                }
+                if constexpr (MODE != 0) {
+                    float d = 0.0f;
+                    if (m < 6 && smp < B) {
+                        if constexpr (MODE == 1) {
+                            const float diff = o - y[smp * 6 + m];
+                            loss_acc += diff * diff;
+                            d = 2.0f * diff * dscale;
+                        } else {
+                            d = dout[smp * 6 + m];
+                        }
+                    }
+                    lds[L_DO + m * SP + i] = d;
+                }
+            }
+        }
+        if constexpr (MODE == 0) {
+            __syncthreads();
+            continue;
+        }
+        __syncthreads();
+        // ---- backward (data path)
+        // dT[j][s] = sum_m L2[m][j] dO[m][s];  dU = dT (1 - T^2): 4 units (j-tiles)
+        if (wave < 4) {
+            const float *l2 = prm + P_L2W;
+            const int j = wave * 16 + i;
+            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {           // m = 0..7 (rows >= 6 of dO are zero)
+                const int m = t + 2 * g;
+                acc = mma(m < 6 ? l2[m * 64 + j] : 0.0f, lds[L_DO + m * SP + i], acc);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float tv = lds[L_TT + (wave * 16 + 4 * g + r) * SP + i];
+                acc[r] *= (1.0f - tv * tv);
+            }
+            put_tile(lds + L_DU, SP, wave * 16, 0, acc, i, g);
+        }
+        __syncthreads();
+        // dH4[c][w*16+s] = sum_j L1[j][c*6+w] dU[j][s];  dZ4 = dH4 * (H4 > 0): 12 units (ct, w)
+        for (int u = wave; u < 12; u += WAVES) {
+            const int ct = u / 6, w = u % 6;
+            const float *l1 = prm + P_L1W;
+            const int c = ct * 16 + i;
+            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+            for (int t = 0; t < 16; ++t) {
+                const int j = t + 16 * g;
+                acc = mma(l1[j * 192 + c * 6 + w], lds[L_DU + j * SP + i], acc);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float hv = lds[L_H4 + (ct * 16 + 4 * g + r) * NP + w * 16 + i];
+                acc[r] = hv > 0.0f ? acc[r] : 0.0f;
+            }
+            put_tile(lds + L_Z4, NP, ct * 16, w * 16, acc, i, g);
+        }
+        __syncthreads();
+        conv_bwd_data_layer<32, 32>(lds, prm + P_C4W, L_Z4, L_H3, L_Z3, wave, i, g);
+        __syncthreads();
+        conv_bwd_data_layer<32, 32>(lds, prm + P_C3W, L_Z3, L_H2, L_Z2, wave, i, g);
+        __syncthreads();
+        conv_bwd_data_layer<16, 32>(lds, prm + P_C2W, L_Z2, L_H1, L_Z1, wave, i, g);
+        __syncthreads();
+        // ---- weight gradients: every tile owned by one wave, accumulated in registers
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+            const int id = s * WAVES + wave;
+            if (id < NTILES) {
+                const GradTile t = grad_tile(id);
+                const float *ap = lds + t.a_off + i * t.a_stride + t.ka0 + g;
+                const float *bp = lds + t.b_off + i * t.b_stride + t.kb0 + g;
+                f32x4 acc = gacc[s];
+#pragma unroll 4
+                for (int k = 0; k < t.steps; ++k) acc = mma(ap[4 * k], bp[4 * k], acc);
+                gacc[s] = acc;
+            }
+        }
+        __syncthreads();
+    }
+
+    if constexpr (MODE != 0) {
+        // tile space out: [block][tile id][r*64 + lane]
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+            const int id = s * WAVES + wave;
+            if (id < NTILES) {
+                float *dst = gtiles + ((size_t)blockIdx.x * NTILES + id) * 256;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[r * 64 + lane] = gacc[s][r];
+            }
+        }
+        if constexpr (MODE == 1) {
+            const float ls = wave_sum(loss_acc);     // only wave 0 holds non-zero sums
+            if (tid == 0) loss_part[blockIdx.x] = ls;
+        }
+    }
+}
+
+// tile element (row R, col C) -> index inside a tile's 256 floats
+__device__ __forceinline__ int tile_elem(int R, int C) { return (R & 3) * 64 + (R >> 2) * 16 + C; }
+
+// parameter index -> (tile id, element)
+__device__ __forceinline__ void param_src(int p, int &id, int &el)
+{
+    if (p < P_C1B) {                       // conv1.weight (16,1,2,1): o*2 + kh -> extras col 1 + kh
+        id = 16; el = tile_elem(p >> 1, 1 + (p & 1));
+    } else if (p < P_C2W) {                // conv1.bias
+        id = 16; el = tile_elem(p - P_C1B, 0);
+    } else if (p < P_C2B) {                // conv2.weight (32,16,3,1)
+        const int q = p - P_C2W, kh = q % 3, c = (q / 3) % 16, o = q / 48;
+        if (kh == 1) { id = 12 + (o >> 4); el = tile_elem(o & 15, c); }
+        else         { id = 14 + (o >> 4); el = tile_elem(o & 15, kh == 0 ? 1 : 2); }
+    } else if (p < P_C3W) {                // conv2.bias
+        const int o = p - P_C2B; id = 14 + (o >> 4); el = tile_elem(o & 15, 0);
+    } else if (p < P_C3B || (p >= P_C4W && p < P_C4B)) {   // conv3 / conv4 weight (32,32,3,1)
+        const bool l4 = p >= P_C4W;
+        const int q = p - (l4 ? P_C4W : P_C3W), kh = q % 3, c = (q / 3) % 32, o = q / 96;
+        const int base = l4 ? 0 : 6;
+        if (kh == 1) { id = base + (o >> 4) * 2 + (c >> 4); el = tile_elem(o & 15, c & 15); }
+        else         { id = base + 4 + (o >> 4); el = tile_elem(o & 15, kh == 0 ? 1 : 2); }
+    } else if (p < P_C4W) {                // conv3.bias
+        const int o = p - P_C3B; id = 10 + (o >> 4); el = tile_elem(o & 15, 0);
+    } else if (p < P_L1W) {                // conv4.bias
+        const int o = p - P_C4B; id = 4 + (o >> 4); el = tile_elem(o & 15, 0);
+    } else if (p < P_L1B) {                // linear1.weight (64,192): j*192 + c*6 + w
+        const int q = p - P_L1W, j = q / 192, cw = q % 192, c = cw / 6, w = cw % 6;
+        id = 17 + ((j >> 4) * 6 + w) * 2 + (c >> 4); el = tile_elem(j & 15, c & 15);
+    } else if (p < P_L2W) {                // linear1.bias
+        const int j = p - P_L1B; id = 65 + (j >> 4); el = tile_elem(j & 15, 0);
+    } else if (p < P_L2B) {                // linear2.weight (6,64): m*64 + j
+        const int q = p - P_L2W, m = q >> 6, j = q & 63;
+        id = 69 + (j >> 4); el = tile_elem(m, j & 15);
+    } else {                               // linear2.bias
+        id = 73; el = tile_elem(p - P_L2B, 0);
+    }
+}
+
+__global__ __launch_bounds__(256) void model_grad_finalize_kernel(const float *__restrict__ gtiles,
+                                                                  const float *__restrict__ loss_part,
+                                                                  int nblocks, float *__restrict__ grads,
+                                                                  float *__restrict__ loss, float loss_scale)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p < NPARAM) {
+        int id, el;
+        param_src(p, id, el);
+        double s = 0.0;
+        for (int b = 0; b < nblocks; ++b) s += (double)gtiles[((size_t)b * NTILES + id) * 256 + el];
+        grads[p] = (float)s;
+    }
+    if (p == 0 && loss && loss_part) {
+        double s = 0.0;
+        for (int b = 0; b < nblocks; ++b) s += (double)loss_part[b];
+        *loss = (float)(s * (double)loss_scale);
+    }
+}
+
+// torch.optim.Adam defaults semantics (newConvolution.py:225): no weight decay, no amsgrad
+__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ gr,
+                                                   float *__restrict__ m, float *__restrict__ v,
+                                                   long long count, float lr, float b1, float b2,
+                                                   float eps, float bc1, float bc2_sqrt, float gscale)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= count) return;
+    const float gv = gr[idx] * gscale;
+    const float mn = b1 * m[idx] + (1.0f - b1) * gv;
+    const float vn = b2 * v[idx] + (1.0f - b2) * gv * gv;
+    m[idx] = mn;
+    v[idx] = vn;
+    const float denom = sqrtf(vn) / bc2_sqrt + eps;
+    p[idx] = p[idx] - (lr / bc1) * (mn / denom);
+}
+
+int model_grid(long long B)
+{
+    const long long ntiles = (B + TS - 1) / TS;
+    long long g = wm_num_cus();
+    if (g > ntiles) g = ntiles;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+template <int MODE>
+int model_launch(const float *prm, const float *x, const float *y, const float *dout, float *out,
+                 float *gtiles, float *loss_part, long long B, float dscale, int grid,
+                 hipStream_t st)
+{
+    static bool attr_set[3] = {false, false, false};
+    if (!attr_set[MODE]) {
+        WM_HIP(hipFuncSetAttribute((const void *)model_kernel<MODE>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+        attr_set[MODE] = true;
+    }
+    hipLaunchKernelGGL((model_kernel<MODE>), dim3(grid), dim3(THREADS), LDS_BYTES, st, prm, x, y,
+                       dout, out, gtiles, loss_part, B, dscale);
+    WM_LAUNCH_CHECK("model_kernel");
+    return WM_OK;
+}
+
+}  // namespace
+
+extern "C" int wm_model_param_count(void) { return NPARAM; }
+
+extern "C" size_t wm_model_workspace_bytes(int64_t B)
+{
+    if (B <= 0 || wm_num_cus() <= 0) return 0;
+    const size_t blocks = (size_t)wm_num_cus();
+    return wm_align_up(blocks * NTILES * 256 * sizeof(float) + blocks * sizeof(float) + 256, 256);
+}
+
+extern "C" int wm_model_fwd_f32(const float *params, const float *x, float *out, int64_t B,
+                                void *stream)
+{
+    WM_REQUIRE(params && x && out, WM_ERR_INVALID, "wm_model_fwd_f32: null pointer");
+    WM_REQUIRE(B >= 0, WM_ERR_INVALID, "wm_model_fwd_f32: negative batch");
+    if (B == 0) return WM_OK;
+    WM_REQUIRE(wm_num_cus() > 0, WM_ERR_NO_DEVICE, "wm_model_fwd_f32: no HIP device");
+    return model_launch<0>(params, x, nullptr, nullptr, out, nullptr, nullptr, B, 0.0f,
+                           model_grid(B), (hipStream_t)stream);
+}
+
+extern "C" int wm_model_train_f32(const float *params, const float *x, const float *y,
+                                  const float *dout, float *out, float *loss, float *grads,
+                                  void *workspace, size_t workspace_bytes, int64_t B,
+                                  int64_t B_global, void *stream)
+{
+    WM_REQUIRE(params && x && out && grads, WM_ERR_INVALID, "wm_model_train_f32: null pointer");
+    WM_REQUIRE((y != nullptr) != (dout != nullptr), WM_ERR_INVALID,
+               "wm_model_train_f32: pass exactly one of y (fused MSE) and dout (given gradient)");
+    WM_REQUIRE(B > 0 && B_global >= B, WM_ERR_INVALID, "wm_model_train_f32: bad batch sizes");
+    WM_REQUIRE(wm_num_cus() > 0, WM_ERR_NO_DEVICE, "wm_model_train_f32: no HIP device");
+    const size_t need = wm_model_workspace_bytes(B);
+    WM_REQUIRE(workspace && workspace_bytes >= need, WM_ERR_WORKSPACE,
+               "wm_model_train_f32: workspace of %zu bytes needed, %zu given", need,
+               workspace_bytes);
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = model_grid(B);
+    float *gtiles = (float *)workspace;
+    float *loss_part = gtiles + (size_t)wm_num_cus() * NTILES * 256;
+    const float dscale = 1.0f / (6.0f * (float)B_global);
+    int rc;
+    if (y) rc = model_launch<1>(params, x, y, nullptr, out, gtiles, loss_part, B, dscale, grid, st);
+    else   rc = model_launch<2>(params, x, nullptr, dout, out, gtiles, loss_part, B, dscale, grid, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(model_grad_finalize_kernel, dim3((NPARAM + 255) / 256), dim3(256), 0, st,
+                       gtiles, y ? loss_part : (const float *)nullptr, grid, grads,
+                       y ? loss : (float *)nullptr, dscale);
+    WM_LAUNCH_CHECK("model_grad_finalize_kernel");
+    return WM_OK;
+}
+
+extern "C" int wm_adam_step_f32(float *params, const float *grads, float *m, float *v,
+                                int64_t count, int step, float lr, float beta1, float beta2,
+                                float eps, float grad_scale, void *stream)
+{
+    WM_REQUIRE(params && grads && m && v, WM_ERR_INVALID, "wm_adam_step_f32: null pointer");
+    WM_REQUIRE(count >= 0 && step >= 1, WM_ERR_INVALID, "wm_adam_step_f32: bad count/step");
+    if (count == 0) return WM_OK;
+    const float bc1 = 1.0f - powf(beta1, (float)step);
+    const float bc2 = 1.0f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, params, grads, m, v, (long long)count, lr, beta1, beta2,
+                       eps, bc1, sqrtf(bc2), grad_scale);
+    WM_LAUNCH_CHECK("adam_kernel");
+    return WM_OK;
+}

@@ -248,3 +248,87 @@ def synth_regression(n, F, P, seed, beta, intercept=0.5, noise=0.01, dist="unifo
             X.data_ptr(), Y.data_ptr(), n, F, P, int(seed), int(row_offset), beta.data_ptr(),
             float(intercept), float(noise), 0 if dist == "uniform" else 1, _stream()))
     return X, Y
+
+
+# --------------------------------------------------------------------------- fused model
+
+MODEL_PARAM_SHAPES = (
+    ("conv1.weight", (16, 1, 2, 1)), ("conv1.bias", (16,)),
+    ("conv2.weight", (32, 16, 3, 1)), ("conv2.bias", (32,)),
+    ("conv3.weight", (32, 32, 3, 1)), ("conv3.bias", (32,)),
+    ("conv4.weight", (32, 32, 3, 1)), ("conv4.bias", (32,)),
+    ("linear1.weight", (64, 192)), ("linear1.bias", (64,)),
+    ("linear2.weight", (6, 64)), ("linear2.bias", (6,)),
+)
+MODEL_PARAM_COUNT = 20566
+
+
+def _model_x(x):
+    """(B,2,6), (B,1,2,6) or the reference's single (1,2,6)/(2,6) sample -> contiguous (B,2,6)."""
+    x = _req(x, "x")
+    if x.dim() == 2:
+        x = x.unsqueeze(0)
+    if x.dim() == 4 and x.shape[1] == 1:
+        x = x.squeeze(1)
+    if x.dim() != 3 or x.shape[1:] != (2, 6):
+        raise ValueError(f"model input must be (B,2,6) or (B,1,2,6), got {tuple(x.shape)}")
+    return x.contiguous()
+
+
+def model_forward(flat_params, x):
+    p = _req(flat_params, "params")
+    if p.numel() != MODEL_PARAM_COUNT:
+        raise ValueError(f"params must hold {MODEL_PARAM_COUNT} floats, got {p.numel()}")
+    x = _model_x(x)
+    B = x.shape[0]
+    out = torch.empty((B, 6), device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().wm_model_fwd_f32(p.data_ptr(), x.data_ptr(), out.data_ptr(), B,
+                                               _stream()))
+    return out
+
+
+def model_train(flat_params, x, y=None, dout=None, batch_global=None, ws=None):
+    """forward + backward.  Returns (out (B,6), loss (0-dim tensor or None), grads (20566,))."""
+    p = _req(flat_params, "params")
+    x = _model_x(x)
+    B = x.shape[0]
+    if (y is None) == (dout is None):
+        raise ValueError("pass exactly one of y and dout")
+    t = _req(y if y is not None else dout, "y/dout").reshape(B, 6).contiguous()
+    L = _lib.lib()
+    out = torch.empty((B, 6), device=x.device, dtype=torch.float32)
+    grads = torch.empty((MODEL_PARAM_COUNT,), device=x.device, dtype=torch.float32)
+    loss = torch.zeros((), device=x.device, dtype=torch.float32) if y is not None else None
+    with torch.cuda.device(x.device):
+        if ws is None:
+            ws = torch.empty((L.wm_model_workspace_bytes(B),), device=x.device, dtype=torch.uint8)
+        _lib.check(L.wm_model_train_f32(
+            p.data_ptr(), x.data_ptr(), t.data_ptr() if y is not None else 0,
+            t.data_ptr() if dout is not None else 0, out.data_ptr(),
+            loss.data_ptr() if loss is not None else 0, grads.data_ptr(), ws.data_ptr(),
+            ws.numel(), B, int(batch_global or B), _stream()))
+    return out, loss, grads
+
+
+def adam_step(params, grads, m, v, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    with torch.cuda.device(params.device):
+        _lib.check(_lib.lib().wm_adam_step_f32(params.data_ptr(), grads.data_ptr(), m.data_ptr(),
+                                               v.data_ptr(), params.numel(), int(step), lr, beta1,
+                                               beta2, eps, grad_scale, _stream()))
+
+
+class ModelFunction(torch.autograd.Function):
+    """out = CustomModel(x) with the fused kernels; backward receives dL/dout from autograd
+    (e.g. from nn.MSELoss, newConvolution.py:181-184) and returns the flat parameter gradient."""
+
+    @staticmethod
+    def forward(ctx, flat_params, x):
+        ctx.save_for_backward(flat_params, x)
+        return model_forward(flat_params, x)
+
+    @staticmethod
+    def backward(ctx, gout):
+        flat_params, x = ctx.saved_tensors
+        _, _, grads = model_train(flat_params, x, dout=gout.contiguous())
+        return grads, None
