@@ -247,12 +247,93 @@ def run_conv(steps, warmup, rank, world, cpu_base, N=64, H=721, W=1440):
     return res
 
 
+# ------------------------------------------------------------------------------ fused model
+def run_model(steps, warmup, rank, world, cpu_base, B=721 * 1440):
+    """BASELINE configs[3] (4a): the reference-shaped 32-channel conv model, forward + backward +
+    Adam on one 721x1440 slice of grid points per GPU per step; DP = one gradient all-reduce."""
+    from weather_model_amd import ops, synth, _lib
+    import torch.distributed as dist
+    L = _lib.lib()
+    parts = []
+    for k, (name, shp) in enumerate(ops.MODEL_PARAM_SHAPES):
+        fan = int(np.prod(shp[1:])) if len(shp) > 1 else {16: 2, 32: 48 if "conv2" in name else 96,
+                                                          64: 192, 6: 64}[shp[0]]
+        bnd = 1.0 / np.sqrt(fan)
+        parts.append(synth.uniform(900 + k, shp, -bnd, bnd).reshape(-1))
+    params = torch.from_numpy(np.concatenate(parts)).cuda()
+    m = torch.zeros_like(params)
+    v = torch.zeros_like(params)
+    x = ops.synth_uniform((B, 2, 6), seed=20, offset=rank * B * 12)
+    y = ops.synth_uniform((B, 6), seed=21, offset=rank * B * 6)
+    out = torch.empty((B, 6), device="cuda")
+    grads = torch.empty_like(params)
+    loss = torch.zeros((), device="cuda")
+    ws = torch.empty((L.wm_model_workspace_bytes(B),), device="cuda", dtype=torch.uint8)
+    evs = []
+    state = {"step": 0}
+
+    def step(i, timed):
+        st = torch.cuda.current_stream().cuda_stream
+        if timed:
+            e = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            e[0].record()
+        _lib.check(L.wm_model_train_f32(params.data_ptr(), x.data_ptr(), y.data_ptr(), 0,
+                                        out.data_ptr(), loss.data_ptr(), grads.data_ptr(),
+                                        ws.data_ptr(), ws.numel(), B, B * world, st))
+        if timed:
+            e[1].record()
+            evs.append(e)
+        if world > 1:
+            dist.all_reduce(grads)           # 82 KB flat gradient buffer, one collective
+        state["step"] += 1
+        _lib.check(L.wm_adam_step_f32(params.data_ptr(), grads.data_ptr(), m.data_ptr(),
+                                      v.data_ptr(), params.numel(), state["step"], 1e-3, 0.9,
+                                      0.999, 1e-8, 1.0, st))
+
+    loss0 = None
+    total = timed_steps(step, steps, warmup, world)
+    kms = float(np.mean([a.elapsed_time(c) for a, c in evs]))
+    flops = 353664.0                       # SURVEY 8d: algorithmic fwd+bwd flops per sample
+    ach = flops * B / (kms * 1e-3) / 1e12
+    res = {"value": B * world * steps / total, "unit": "grid-pts/s",
+           "ms_per_step": total / steps * 1e3, "train_kernel_ms": kms,
+           "final_loss": float(loss) * world,
+           "config": {"workload": "newConvolution.CustomModel (1->16->32->32->32 conv stack + "
+                                  "192->64->6 head) fwd+bwd+Adam, 1038240 grid points per GPU per step"},
+           "roofline": {"bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF,
+                        "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF, "traffic": None,
+                        "kernel": "model_kernel<1>", "algorithmic_flops_per_sample": flops}}
+    if cpu_base and rank == 0 and world == 1:
+        from oracle import model_ref
+        nb = 16384
+        xs, ys = x[:nb].cpu().numpy(), y[:nb].cpu().numpy()
+        pd, off = {}, 0
+        pc = params.cpu().numpy()
+        for name, shp in ops.MODEL_PARAM_SHAPES:
+            k = int(np.prod(shp))
+            pd[name] = pc[off:off + k].reshape(shp)
+            off += k
+        best, reps = 1e30, 0
+        t_end = time.perf_counter() + 10.0
+        while reps < 2 or (time.perf_counter() < t_end and reps < 30):
+            t0 = time.perf_counter()
+            model_ref.loss_and_grads(pd, xs, ys)
+            best = min(best, time.perf_counter() - t0)
+            reps += 1
+        res["cpu_baseline"] = {"value": nb / best, "unit": "grid-pts/s",
+                               "cores": int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1)),
+                               "kind": "port",
+                               "sample": f"{nb} samples, oracle/model_ref.py (numpy float64 batched "
+                                         f"fwd+bwd, BLAS threads), best of {reps}"}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="all", choices=["all", "gram16", "conv3x3", "gram64"])
+    ap.add_argument("--workload", default="all", choices=["all", "gram16", "conv3x3", "gram64", "model32"])
     ap.add_argument("--rows", type=int, default=100_000_000, help="rows per GPU (gram workloads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -293,6 +374,16 @@ def main():
                 out["cpu_baseline"] = c["cpu_baseline"]
         else:
             out["also"] = {"conv3x3": c}
+    if args.workload in ("all", "model32"):
+        mres = run_model(args.steps, args.warmup, rank, world, cpu_base)
+        if args.workload == "model32":
+            out.update({"metric": "grid-pts/s model fwd+bwd", "unit": "grid-pts/s",
+                        "value": mres["value"], "ms_per_step": mres["ms_per_step"],
+                        "roofline": mres["roofline"], "config": mres["config"]})
+            if "cpu_baseline" in mres:
+                out["cpu_baseline"] = mres["cpu_baseline"]
+        else:
+            out.setdefault("also", {})["model32"] = mres
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -136,3 +136,29 @@ def test_large_batch_properties():
     _, l3, g3 = ops.model_train(p, x[:4096], y=y[:4096])
     assert abs(float(l3) - ol) < 1e-5 * ol
     assert relinf(g3.cpu().numpy(), _flat(og)) < TOL
+
+
+def test_dropin_module_reproduces_reference_training(model_golden):
+    """weather_model_amd.dropin.newConvolution: the reference's call sequence
+    (model(x); loss_fn; loss.backward(); optimizer.step(); zero_grad) on the reference's weights."""
+    from weather_model_amd.dropin import newConvolution as nc
+    g = model_golden
+    sd = {k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd0/")}
+    model = nc.CustomModel((2, 6))
+    model.load_state_dict(sd, strict=True)
+    x = torch.from_numpy(g["x"])            # (64,1,2,6) CPU tensors, as the DataLoader yields them
+    y = torch.from_numpy(g["y"])
+    out = model(x[0])                       # the reference call: (1,2,6) -> (1,6)
+    assert out.shape == (1, 6)
+    assert relinf(out.detach().cpu().numpy(), g["out"][0:1]) < TOL
+    outb = model(x[:, 0])                   # batched
+    assert relinf(outb.detach().cpu().numpy(), g["out"]) < TOL
+    loss_fn = torch.nn.MSELoss()
+    opt = torch.optim.Adam(model.parameters())
+    data = [(x[i], y[i]) for i in range(3)]
+    nc.training_loop(data, model, loss_fn, opt, 3, 0)
+    ref = {k[6:]: g[k] for k in g.files if k.startswith("adam3/")}
+    for k, v in model.state_dict().items():
+        assert np.abs(v.cpu().numpy() - ref[k]).max() < 2e-5, k
+    correct, total, _ = nc.testing_loop([(x[i], y[i]) for i in range(8)], model, loss_fn)
+    assert total == 8 and 0 <= correct <= 8

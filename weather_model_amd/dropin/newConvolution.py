@@ -1,0 +1,261 @@
+"""Drop-in mirror of the reference's ``newConvolution.py`` for the hot path.
+
+Same module-level names, signatures and tensor shapes as /root/reference/newConvolution.py; the
+arithmetic of ``CustomModel`` runs in the fused gfx950 kernels of libwm.so (csrc/model.hip) instead
+of ``aten::conv2d`` + 160 ``torch.cat`` calls per sample.  Differences a user can see:
+
+* ``CustomModel.forward`` also accepts batches ``(B,2,6)`` / ``(B,1,2,6)`` (the reference only runs
+  batch 1, newConvolution.py:240-241) and returns ``(B,6)``; the reference call ``(1,2,6) -> (1,6)``
+  is unchanged.
+* parameters live on the GPU (there is no CPU path); CPU inputs are moved to the model's device.
+* ``CustomDataset`` has a vectorised ``batch(indices)`` next to the reference's per-item gather.
+"""
+from __future__ import annotations
+
+import glob
+import os
+from math import prod
+
+import numpy as np
+import torch
+from torch import nn
+from torch.utils.data import DataLoader, Dataset
+
+from weather_model_amd import ops
+
+device = "cuda" if torch.cuda.is_available() else "cpu"          # newConvolution.py:10
+data_path = "D:/Documents/Code/research/wrfout"                    # :11
+all_files = [os.path.basename(f) for f in glob.glob(data_path + "/wrfout*")][:35]   # :12
+data_vars = ['T', 'P', 'PB', 'QVAPOR', 'QRAIN', 'QSNOW']          # :13-20
+epochs = 10                                                        # :21
+
+# global value ranges of the WRF variables (data, newConvolution.py:23-45)
+DATA_VARS_MIN = {'T': -8.417083740234375, 'P': -50.28515625, 'PB': 5420.28076171875,
+                 'QVAPOR': 0.0, 'QRAIN': -1.3538986555136634e-12,
+                 'QSNOW': -3.2677986886402296e-15, 'QGRAUP': 0.0, 'U': -14.949191093444824,
+                 'V': -28.35787010192871, 'W': -5.611952781677246,
+                 'QCLOUD': -7.121892919154105e-12}
+DATA_VARS_MAX = {'T': 192.04437255859375, 'P': 1313.625, 'PB': 97532.5546875,
+                 'QVAPOR': 0.02198491431772709, 'QRAIN': 0.0021312725730240345,
+                 'QSNOW': 0.0001476061879657209, 'QGRAUP': 0.0, 'U': 26.568021774291992,
+                 'V': 17.940385818481445, 'W': 8.062047958374023,
+                 'QCLOUD': 0.002458590315654874}
+
+
+def normalize(data, var) -> np.ndarray:
+    """min-max scaling with the tabulated range (newConvolution.py:47-49)."""
+    lo, hi = DATA_VARS_MIN[var], DATA_VARS_MAX[var]
+    return (data.to_numpy() - lo) / (hi - lo)
+
+
+def append_to_array(array1, array2):
+    """Grow a tensor along a new leading axis (newConvolution.py:53-59): None -> array2; equal
+    shapes -> stack of the two; otherwise array2 becomes one more leading slice of array1."""
+    if array1 is None:
+        return array2
+    head = array1.unsqueeze(0) if array1.shape == array2.shape else array1
+    return torch.cat((head, array2.unsqueeze(0)), dim=0)
+
+
+def load_data():
+    """{var: tensor (T,1,Z,Y,X)} of normalised fields (newConvolution.py:62-73).  Collects each
+    variable's files in a list and stacks once (the reference re-concatenates per file)."""
+    import xarray as xr   # only needed here, as in the reference (:66)
+    per_var = {var: [] for var in data_vars}
+    for i, name in enumerate(all_files):
+        ds = xr.open_dataset(f"{data_path}/{name}")
+        print(f"\rLoading data {i}/{len(all_files)}", end='')
+        for var in data_vars:
+            per_var[var].append(torch.from_numpy(normalize(ds[var], var)))
+        ds.close()
+    print("\rLoading data complete")
+    data = {}
+    for var, items in per_var.items():
+        out = None
+        for t in items:
+            out = append_to_array(out, t)
+        data[var] = out
+    return data
+
+
+class CustomDataset(Dataset):
+    """item idx -> (x (2,6), y (6,)): the six variables at one grid point at times t, t+6 (x) and
+    t+3 (y) (newConvolution.py:75-106)."""
+
+    def __init__(self, data, length, shape, time_offset):
+        super().__init__()
+        self.data = data
+        self.length = length
+        self.shape = shape            # time, height, row, column
+        self.time_offset = time_offset
+        self._vol = None
+
+    def __len__(self):
+        return self.length
+
+    def _decode(self, idx):
+        t_, z_, y_, x_ = self.shape
+        column = idx % x_
+        row = (idx // x_) % y_
+        height = (idx // (x_ * y_)) % z_
+        time = (idx // (x_ * y_ * z_)) % t_ + self.time_offset
+        return time, height, row, column
+
+    def gather_data(self, time, height, row, column):
+        return torch.stack([self.data[var][time][0][height][row][column].clone().detach()
+                            for var in data_vars])
+
+    def __getitem__(self, idx):
+        time, height, row, column = self._decode(idx)
+        start_x = self.gather_data(time, height, row, column)
+        end_x = self.gather_data(time + 6, height, row, column)
+        y = self.gather_data(time + 3, height, row, column)
+        return torch.stack((start_x, end_x), dim=0), y
+
+    def batch(self, indices, device=None):
+        """Vectorised gather of many items: x (B,2,6), y (B,6)."""
+        if self._vol is None or (device is not None and self._vol.device != torch.device(device)):
+            vol = torch.stack([self.data[var][:, 0] for var in data_vars], dim=-1)   # (T,Z,Y,X,6)
+            self._vol = vol.to(device) if device is not None else vol
+        idx = torch.as_tensor(indices, device=self._vol.device, dtype=torch.long)
+        time, height, row, column = self._decode(idx)
+        g = lambda t: self._vol[t, height, row, column]                                # noqa: E731
+        return torch.stack((g(time), g(time + 6)), dim=1), g(time + 3)
+
+
+class CustomModel(nn.Module):
+    """Same parameters, names and shapes as the reference (newConvolution.py:109-137) so a
+    reference ``state_dict`` loads strictly -- including the dead ``seq_module`` (:113-127), which
+    never runs.  ``forward`` = one fused HIP launch."""
+
+    def __init__(self, input_shape):
+        super().__init__()
+        self.seq_module = nn.Sequential(                   # dead parameters, kept for state_dict
+            nn.Conv2d(1, 8, kernel_size=(2, 1), stride=1), nn.ReLU(),
+            nn.Conv2d(8, 16, kernel_size=(1, 2), stride=1), nn.ReLU(),
+            nn.Conv2d(16, 32, kernel_size=(1, 2), stride=1), nn.ReLU(),
+            nn.Conv2d(32, 32, kernel_size=(1, 2), stride=1), nn.ReLU(),
+            nn.Conv2d(32, 32, kernel_size=(1, 2), stride=1), nn.ReLU(),
+            nn.Flatten(0, -1),
+            nn.Linear(32 * prod((1, 2)), 64),
+            nn.Linear(64, len(data_vars)),
+        )
+        self.conv1 = nn.Conv2d(1, 16, kernel_size=(2, 1), stride=1)
+        self.relu = nn.ReLU()
+        self.conv2 = nn.Conv2d(16, 32, kernel_size=(3, 1), stride=1)
+        self.conv3 = nn.Conv2d(32, 32, kernel_size=(3, 1), stride=1)
+        self.conv4 = nn.Conv2d(32, 32, kernel_size=(3, 1), stride=1)
+        self.flatten = nn.Flatten(0, -1)
+        self.linear1 = nn.Linear(32 * prod((6, 1)), 64)
+        self.linear2 = nn.Linear(64, len(data_vars))
+        self.tanh = nn.Tanh()
+        if torch.cuda.is_available():
+            self.to("cuda")
+
+    def _path_parameters(self):
+        return [self.get_parameter(name) for name, _ in ops.MODEL_PARAM_SHAPES]
+
+    def flat_parameters(self):
+        """The 20566 forward-path parameters as one vector (autograd flows back to each)."""
+        return torch.cat([p.reshape(-1) for p in self._path_parameters()])
+
+    def concatenate_bounds(self, start, x, end, channels):
+        """(C,1,6) -> (C,3,6): [start; x_c; end] for every channel (newConvolution.py:139-144).
+        The fused kernel never materialises this; kept for API parity."""
+        s = start.to(x.device).expand(channels, -1, -1) if start.dim() == 3 else \
+            start.to(x.device).unsqueeze(0).expand(channels, -1, -1)
+        e = end.to(x.device).expand(channels, -1, -1) if end.dim() == 3 else \
+            end.to(x.device).unsqueeze(0).expand(channels, -1, -1)
+        return torch.cat((s, x[:channels], e), dim=1)
+
+    def forward(self, x):
+        dev = self.conv1.weight.device
+        x = torch.as_tensor(x, dtype=torch.float32).to(dev)
+        return ops.ModelFunction.apply(self.flat_parameters(), x)
+
+
+def calculate_average(x):
+    """The two-point temporal average baseline (newConvolution.py:166-172): (1,6) for one sample,
+    (B,6) for a batch."""
+    x = torch.as_tensor(x)
+    x = x.reshape(-1, 2, len(data_vars))
+    return (x[:, 0] + x[:, 1]) / 2.0
+
+
+def training_loop(data, model, loss_fn, optimizer, length, epoch):
+    """forward -> loss -> backward -> step -> zero_grad per batch (newConvolution.py:174-194)."""
+    model.train()
+    dev = next(model.parameters()).device
+    counter, total_loss = 0, 0.0
+    for batch, (x, y) in enumerate(data):
+        counter += 1
+        prediction = model(x)
+        loss = loss_fn(prediction, y.to(dev).reshape(prediction.shape))
+        total_loss += loss.item()
+        loss.backward()
+        optimizer.step()
+        optimizer.zero_grad()
+        if batch % 10 == 0:
+            filled = int((counter / length) * 20)
+            print(f"\rEpoch: {epoch} - {counter}/{length} - |{'#' * filled}{'-' * (20 - filled)}|"
+                  f" - Loss: {loss.item():0.4e} - Avg Loss: {(total_loss / counter):0.4e}", end='')
+    print(f"\rEpoch: {epoch} - Complete - Avg Loss: {(total_loss / max(counter, 1)):0.4e}")
+    return total_loss / max(counter, 1)
+
+
+def testing_loop(data, model, loss_fn):
+    """Counts how often the model beats the two-point average (newConvolution.py:197-216)."""
+    model.eval()
+    dev = next(model.parameters()).device
+    counter = correct = total = 0
+    total_loss = 0.0
+    for x, y in data:
+        counter += 1
+        with torch.no_grad():
+            prediction = model(x)
+            yd = y.to(dev).reshape(prediction.shape)
+            average = calculate_average(x).to(dev).reshape(prediction.shape)
+            pred_l = ((prediction - yd) ** 2).mean(dim=1)
+            avg_l = ((average - yd) ** 2).mean(dim=1)
+            correct += int((pred_l < avg_l).sum())
+            total += int(pred_l.numel())
+            prediction_loss = loss_fn(prediction, yd).item()
+            average_loss = loss_fn(average, yd).item()
+            total_loss += prediction_loss
+        print(f"\rAccuracy: {(correct / total):0.2f}% - {correct}/{total} | "
+              f"Pred_loss: {prediction_loss} Avg_loss: {average_loss}", end="")
+    print(f"\rAccuracy: {(correct / max(total, 1)):0.2f}% - Validation Loss: "
+          f"{(total_loss / max(counter, 1)):0.4e}")
+    return correct, total, total_loss / max(counter, 1)
+
+
+def main(batch_size=1):
+    """The reference's script entry (newConvolution.py:219-255); batch_size > 1 uses the batched
+    kernels (the reference is fixed at 1)."""
+    validation_split = 0.8
+    model = CustomModel((2, len(data_vars)))
+    loss_fn = nn.MSELoss()
+    optimizer = torch.optim.Adam(model.parameters())
+    data = load_data()
+    if any(v is None for v in data.values()):
+        return
+    data_shape = data[data_vars[0]].shape
+    shape = (int((data_shape[0] * validation_split) - 6), data_shape[2] - 40,
+             data_shape[3] - 200, data_shape[4] - 200)
+    length = int(prod(shape))
+    train_loader = DataLoader(CustomDataset(data, length, shape, 0), batch_size=batch_size,
+                              shuffle=True)
+    test_shape = (round((data_shape[0] * (1 - validation_split)) - 6), data_shape[2] - 40,
+                  data_shape[3] - 200, data_shape[4] - 200)
+    test_length = int(prod(shape))       # the reference reuses the train shape here (:247)
+    test_loader = DataLoader(CustomDataset(data, test_length, test_shape,
+                                           int(data_shape[0] * validation_split)),
+                             batch_size=batch_size, shuffle=False)
+    for epoch in range(epochs):
+        training_loop(train_loader, model, loss_fn, optimizer, length, epoch)
+        testing_loop(test_loader, model, loss_fn)
+    print("Done, hooray!")
+
+
+if __name__ == "__main__":
+    main()
