@@ -138,3 +138,28 @@ def test_full_size_property_recovers_planted_coefficients():
     from oracle import cpu as ocpu
     Xs, Ys = X[:200000].cpu().numpy(), Y[:200000].cpu().numpy()
     assert relinf(ops.gram(X[:200000], Y[:200000]).cpu().numpy(), ocpu.gram(Xs, Ys)) < 2e-6
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 5, 31, 257, 4 * 8 * 64 * 3 + 7, 50001])
+def test_gram_x64_ragged_row_counts(n):
+    from weather_model_amd import ops, synth
+    from oracle import cpu as ocpu
+    X, Y, _ = synth.regression_problem(n, 64, 1, seed=41)
+    a = ops.gram(_dev(X), _dev(Y)).cpu().numpy()
+    assert relinf(a, ocpu.gram(X, Y)) < 2e-6
+    assert a[64, 64] == n
+    assert np.array_equal(a, a.T)
+
+
+def test_gram_x64_asymmetric_integers_are_exact():
+    """Small distinct integers: every product and sum is exact in float32, so the 66x66 Gram
+    must equal the oracle bit for bit; any operand/result map slip permutes entries."""
+    from weather_model_amd import ops
+    from oracle import cpu as ocpu
+    n = 1029
+    r = np.arange(n, dtype=np.float32)[:, None]
+    f = np.arange(64, dtype=np.float32)[None, :]
+    X = ((r * 7 + f * f * 3 + f * 5) % 11) + (f % 7)
+    Y = ((r * 5) % 13) - 4.0
+    a = ops.gram(_dev(X), _dev(Y)).cpu().numpy()
+    assert np.array_equal(a, ocpu.gram(X, Y))

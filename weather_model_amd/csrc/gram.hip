@@ -202,6 +202,180 @@ __global__ __launch_bounds__(64) void gram_f16_finalize_kernel(const double *__r
     if (threadIdx.x == 0) acc[e] += s;
 }
 
+// ---------------------------------------------------------------------------- F = 64, P = 1
+// BASELINE config 5.  A row is 256 B, so one 1 KiB dwordx4 wave-load holds 4 rows: lane (i, g) =
+// (lane & 15, lane >> 4) gets features 4i..4i+3 of row g.  Register q of all 64 lanes is then both
+// the A and the B operand of v_mfma_f32_16x16x4_f32 for the feature set S_q = {4i+q}: A = reg q1,
+// B = reg q2 accumulates the 16x16 block of the Gram between S_q1 and S_q2 (row a, column b =
+// features 4a+q1, 4b+q2), k = the 4 rows.  The 10 pairs q1 <= q2 cover the symmetric 64x64 block
+// (10/16 of the full product), with no LDS, no transposition and one coalesced load per 4 rows.
+constexpr int X64_NPAIR = 10;
+constexpr int X64_NVAL = X64_NPAIR * 4 + 4 + 4 + 2;     // per-lane float64 values
+constexpr int X64_PART = X64_NPAIR * 256 + 64 + 64 + 2;  // per-wave doubles written out
+constexpr int X64_FLUSH_STEPS = 256;                     // 256 steps x 4 rows = 1024 products
+constexpr int X64_UNROLL = 8;
+
+struct X64Acc {
+    f32x4 g[X64_NPAIR];
+    float xy[4], sx[4], sy, syy;
+};
+
+__device__ __forceinline__ void x64_zero(X64Acc &a)
+{
+#pragma unroll
+    for (int p = 0; p < X64_NPAIR; ++p) a.g[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { a.xy[r] = 0.f; a.sx[r] = 0.f; }
+    a.sy = 0.f;
+    a.syy = 0.f;
+}
+
+__device__ __forceinline__ void x64_step(X64Acc &a, const f32x4 x, const float y)
+{
+    a.g[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.x, x.x, a.g[0], 0, 0, 0);
+    a.g[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.x, x.y, a.g[1], 0, 0, 0);
+    a.g[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.x, x.z, a.g[2], 0, 0, 0);
+    a.g[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.x, x.w, a.g[3], 0, 0, 0);
+    a.g[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.y, x.y, a.g[4], 0, 0, 0);
+    a.g[5] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.y, x.z, a.g[5], 0, 0, 0);
+    a.g[6] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.y, x.w, a.g[6], 0, 0, 0);
+    a.g[7] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.z, x.z, a.g[7], 0, 0, 0);
+    a.g[8] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.z, x.w, a.g[8], 0, 0, 0);
+    a.g[9] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.w, x.w, a.g[9], 0, 0, 0);
+    a.xy[0] = fmaf(x.x, y, a.xy[0]);
+    a.xy[1] = fmaf(x.y, y, a.xy[1]);
+    a.xy[2] = fmaf(x.z, y, a.xy[2]);
+    a.xy[3] = fmaf(x.w, y, a.xy[3]);
+    a.sx[0] += x.x;
+    a.sx[1] += x.y;
+    a.sx[2] += x.z;
+    a.sx[3] += x.w;
+    a.sy += y;
+    a.syy = fmaf(y, y, a.syy);
+}
+
+__device__ __forceinline__ void x64_flush(X64Acc &a, double (&d)[X64_NVAL])
+{
+#pragma unroll
+    for (int p = 0; p < X64_NPAIR; ++p)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d[p * 4 + r] += (double)a.g[p][r];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        d[40 + r] += (double)a.xy[r];
+        d[44 + r] += (double)a.sx[r];
+    }
+    d[48] += (double)a.sy;
+    d[49] += (double)a.syy;
+    x64_zero(a);
+}
+
+// partial: [gridDim.x * WAVES][X64_PART] float64, one slab per wave.
+__global__ __launch_bounds__(BLOCK, 2) void gram_x64_kernel(const float *__restrict__ X,
+                                                            const float *__restrict__ Y,
+                                                            long long n,
+                                                            double *__restrict__ partial)
+{
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int g = lane >> 4, i = lane & 15;
+    const long long nwaves = (long long)gridDim.x * WAVES;
+    const long long wave_id = (long long)blockIdx.x * WAVES + wv;
+    const long long steps = (n + 3) >> 2;           // 4-row steps, the last may be partial
+    const long long full_steps = n >> 2;
+    const long long s0 = steps * wave_id / nwaves;
+    const long long s1 = steps * (wave_id + 1) / nwaves;
+
+    X64Acc a;
+    x64_zero(a);
+    double d[X64_NVAL];
+#pragma unroll
+    for (int v = 0; v < X64_NVAL; ++v) d[v] = 0.0;
+
+    const f32x4 *__restrict__ Xv = reinterpret_cast<const f32x4 *>(X);
+    long long s = s0;
+    int since_flush = 0;
+    const long long s1_full = (s1 < full_steps) ? s1 : full_steps;
+    for (; s + X64_UNROLL <= s1_full; s += X64_UNROLL) {
+        f32x4 xv[X64_UNROLL];
+        float yv[X64_UNROLL];
+#pragma unroll
+        for (int u = 0; u < X64_UNROLL; ++u) {
+            xv[u] = Xv[(s + u) * 64 + lane];
+            yv[u] = Y[(s + u) * 4 + g];
+        }
+#pragma unroll
+        for (int u = 0; u < X64_UNROLL; ++u) x64_step(a, xv[u], yv[u]);
+        since_flush += X64_UNROLL;
+        if (since_flush >= X64_FLUSH_STEPS) {
+            x64_flush(a, d);
+            since_flush = 0;
+        }
+    }
+    for (; s < s1; ++s) {
+        const long long row = s * 4 + g;
+        f32x4 xv = (f32x4){0.f, 0.f, 0.f, 0.f};
+        float yv = 0.f;
+        if (row < n) {
+            xv = Xv[s * 64 + lane];
+            yv = Y[row];
+        }
+        x64_step(a, xv, yv);
+    }
+    x64_flush(a, d);
+
+    double *dst = partial + (size_t)wave_id * X64_PART;
+#pragma unroll
+    for (int p = 0; p < X64_NPAIR; ++p)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[p * 256 + r * 64 + lane] = d[p * 4 + r];
+    // X'y and column sums: lane (i, g) holds rows = g (mod 4); add the four row groups
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        double v = d[40 + q];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (g == 0) dst[2560 + q * 16 + i] = v;      // q<4: xy[q][i], q>=4: sx[q-4][i]
+    }
+    {
+        // y sums: the 16 lanes of a group hold the same y; take one lane per group
+        double sy = d[48], syy = d[49];
+        sy += __shfl_xor(sy, 16, 64);   sy += __shfl_xor(sy, 32, 64);
+        syy += __shfl_xor(syy, 16, 64); syy += __shfl_xor(syy, 32, 64);
+        if (lane == 0) { dst[2688] = sy; dst[2689] = syy; }
+    }
+}
+
+// acc (66x66) += fixed-order sum over the per-wave slabs.  One wave per acc entry.
+__global__ __launch_bounds__(64) void gram_x64_finalize_kernel(const double *__restrict__ partial,
+                                                               int nparts, long long n,
+                                                               double *__restrict__ acc)
+{
+    constexpr int D = 66;
+    const int e = blockIdx.x;
+    const int I = e / D, J = e % D;
+    int idx = -1;
+    if (I < 64 && J < 64) {
+        const int a = I >> 2, q1 = I & 3, b = J >> 2, q2 = J & 3;
+        // tile (q1<=q2): row a, col b  ->  register a&3, lane (a>>2)*16 + b
+        if (q1 <= q2) idx = f16_pair(q1, q2) * 256 + (a & 3) * 64 + (a >> 2) * 16 + b;
+        else          idx = f16_pair(q2, q1) * 256 + (b & 3) * 64 + (b >> 2) * 16 + a;
+    } else if (I < 64 && J == 64) idx = 2560 + (4 + (I & 3)) * 16 + (I >> 2);
+    else if (J < 64 && I == 64) idx = 2560 + (4 + (J & 3)) * 16 + (J >> 2);
+    else if (I < 64 && J == 65) idx = 2560 + (I & 3) * 16 + (I >> 2);
+    else if (J < 64 && I == 65) idx = 2560 + (J & 3) * 16 + (J >> 2);
+    else if ((I == 64 && J == 65) || (I == 65 && J == 64)) idx = 2688;
+    else if (I == 65 && J == 65) idx = 2689;
+    double s = 0.0;
+    if (idx >= 0) {
+        for (int p = threadIdx.x; p < nparts; p += 64) s += partial[(size_t)p * X64_PART + idx];
+        s = wave_sum(s);
+    } else {
+        s = (double)n;
+    }
+    if (threadIdx.x == 0) acc[e] += s;
+}
+
 // ---------------------------------------------------------------------------- generic tiles
 __device__ __forceinline__ float zval(const float *__restrict__ X, const float *__restrict__ Y,
                                       long long row, int col, long long n, int F, int P, int D)
@@ -408,6 +582,21 @@ bool use_f16(const float *X, int F, int P)
     return F == 16 && P == 1 && (((uintptr_t)X) & 15) == 0;
 }
 
+bool use_x64(const float *X, int F, int P)
+{
+    return F == 64 && P == 1 && (((uintptr_t)X) & 15) == 0;
+}
+
+int x64_grid(long long n)
+{
+    // 2 blocks of 4 waves per CU, fewer for small inputs (>= 64 steps per wave)
+    long long g = (long long)wm_num_cus() * 2;
+    const long long cap = (n / 4 + 64 * WAVES - 1) / (64 * WAVES);
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
 int f16_grid()
 {
     // 2 waves per SIMD (launch bounds) = 2 blocks of 4 waves per CU; every block is resident.
@@ -441,6 +630,10 @@ extern "C" size_t wm_gram_workspace_bytes(int64_t n, int F, int P)
         const size_t b16 = (size_t)f16_grid() * F16_PART * sizeof(double);
         if (b16 > b) b = b16;
     }
+    if (F == 64 && P == 1) {
+        const size_t b64 = (size_t)x64_grid(n) * WAVES * X64_PART * sizeof(double);
+        if (b64 > b) b = b64;
+    }
     return wm_align_up(b, 256);
 }
 
@@ -465,6 +658,16 @@ extern "C" int wm_gram_f32(const float *X, const float *Y, int64_t n, int F, int
         hipLaunchKernelGGL(gram_f16_finalize_kernel, dim3(18 * 18), dim3(64), 0, st, partial, grid,
                            (long long)n, acc);
         WM_LAUNCH_CHECK("gram_f16_finalize_kernel");
+        return WM_OK;
+    }
+    if (use_x64(X, F, P)) {
+        const int grid = x64_grid(n);
+        hipLaunchKernelGGL(gram_x64_kernel, dim3(grid), dim3(BLOCK), 0, st, X, Y, (long long)n,
+                           partial);
+        WM_LAUNCH_CHECK("gram_x64_kernel");
+        hipLaunchKernelGGL(gram_x64_finalize_kernel, dim3(66 * 66), dim3(64), 0, st, partial,
+                           grid * WAVES, (long long)n, acc);
+        WM_LAUNCH_CHECK("gram_x64_finalize_kernel");
         return WM_OK;
     }
     int DT, pairs, slices;
