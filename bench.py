@@ -83,8 +83,7 @@ def timed_steps(step, steps, warmup, world):
 
 # ------------------------------------------------------------------------------ regression
 def run_gram(F, n_rows, steps, warmup, rank, world, cpu_base):
-    from weather_model_amd import ops, synth
-    import torch.distributed as dist
+    from weather_model_amd import ops, synth, dp
     P = 1
     beta_true = synth.normal(1001, (F, P))
     # rows of this rank: global row index keeps the data independent of the GPU count
@@ -116,7 +115,7 @@ def run_gram(F, n_rows, steps, warmup, rank, world, cpu_base):
             e[1].record()
             evs.append(e)
         if world > 1:
-            dist.all_reduce(plan.acc)            # the one exchange step: 18x18 float64
+            dp.reduce_gram_(plan.acc)            # the one exchange step: (F+2)x(F+2) float64
         plan.solve()
 
     total = timed_steps(step, steps, warmup, world)
@@ -175,8 +174,7 @@ def run_gram(F, n_rows, steps, warmup, rank, world, cpu_base):
 
 # ------------------------------------------------------------------------------ convolution
 def run_conv(steps, warmup, rank, world, cpu_base, N=64, H=721, W=1440):
-    from weather_model_amd import ops, _lib
-    import torch.distributed as dist
+    from weather_model_amd import ops, _lib, dp
     L = _lib.lib()
     nset = 3        # rotate buffer sets so the 256 MiB Infinity Cache cannot serve the reads
     w = ops.synth_uniform((1, 1, 3, 3), seed=3, lo=-1 / 3, hi=1 / 3)
@@ -209,7 +207,7 @@ def run_conv(steps, warmup, rank, world, cpu_base, N=64, H=721, W=1440):
             fwd_ev.append((e[0], e[1]))
             bwd_ev.append((e[1], e[2]))
         if world > 1:
-            dist.all_reduce(grads)               # DP weight-gradient exchange (10 floats)
+            dp.reduce_grads_(grads)              # DP weight-gradient exchange (10 floats)
 
     total = timed_steps(step, steps, warmup, world)
     pts = N * H * W
@@ -256,8 +254,7 @@ def run_conv(steps, warmup, rank, world, cpu_base, N=64, H=721, W=1440):
 def run_model(steps, warmup, rank, world, cpu_base, B=721 * 1440):
     """BASELINE configs[3] (4a): the reference-shaped 32-channel conv model, forward + backward +
     Adam on one 721x1440 slice of grid points per GPU per step; DP = one gradient all-reduce."""
-    from weather_model_amd import ops, synth, _lib
-    import torch.distributed as dist
+    from weather_model_amd import ops, synth, _lib, dp
     L = _lib.lib()
     parts = []
     for k, (name, shp) in enumerate(ops.MODEL_PARAM_SHAPES):
@@ -289,7 +286,7 @@ def run_model(steps, warmup, rank, world, cpu_base, B=721 * 1440):
             e[1].record()
             evs.append(e)
         if world > 1:
-            dist.all_reduce(grads)           # 82 KB flat gradient buffer, one collective
+            dp.reduce_grads_(grads)          # 82 KB flat gradient buffer, one collective
         state["step"] += 1
         _lib.check(L.wm_adam_step_f32(params.data_ptr(), grads.data_ptr(), m.data_ptr(),
                                       v.data_ptr(), params.numel(), state["step"], 1e-3, 0.9,

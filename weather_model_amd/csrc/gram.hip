@@ -488,16 +488,17 @@ __global__ __launch_bounds__(BLOCK) void normal_solve_kernel(const double *__res
     double *A = USE_LDS ? smem + 2 : ws;
     double *B = A + (size_t)F * F;
     const int tid = threadIdx.x;
+    const int NT = blockDim.x;   // 64 (one wave: barriers are free) for small systems, else 256
     const double n = acc[(size_t)F * D + F];
     const double inv_n = (fit_intercept && n > 0.0) ? 1.0 / n : 0.0;
     if (tid == 0) bad = (fit_intercept && !(n > 0.0)) ? 1 : 0;
-    for (int e = tid; e < F * F; e += BLOCK) {
+    for (int e = tid; e < F * F; e += NT) {
         const int i = e / F, j = e % F;
         double v = acc[(size_t)i * D + j] - acc[(size_t)i * D + F] * acc[(size_t)j * D + F] * inv_n;
         if (i == j) v += ridge;
         A[e] = v;
     }
-    for (int e = tid; e < F * P; e += BLOCK) {
+    for (int e = tid; e < F * P; e += NT) {
         const int i = e / P, p = e % P;
         B[e] = acc[(size_t)i * D + F + 1 + p] -
                acc[(size_t)i * D + F] * acc[(size_t)F * D + F + 1 + p] * inv_n;
@@ -513,10 +514,10 @@ __global__ __launch_bounds__(BLOCK) void normal_solve_kernel(const double *__res
         __syncthreads();
         if (bad) break;
         const double dk = A[(size_t)k * F + k];
-        for (int i = k + 1 + tid; i < F; i += BLOCK) A[(size_t)i * F + k] /= dk;
+        for (int i = k + 1 + tid; i < F; i += NT) A[(size_t)i * F + k] /= dk;
         __syncthreads();
         const int m = F - k - 1;
-        for (int e = tid; e < m * m; e += BLOCK) {
+        for (int e = tid; e < m * m; e += NT) {
             const int i = k + 1 + e / m, j = k + 1 + e % m;
             if (j <= i) A[(size_t)i * F + j] -= A[(size_t)i * F + k] * A[(size_t)j * F + k];
         }
@@ -526,10 +527,10 @@ __global__ __launch_bounds__(BLOCK) void normal_solve_kernel(const double *__res
         // forward substitution L z = B (column oriented), then back substitution L' beta = z
         for (int k = 0; k < F; ++k) {
             const double dk = A[(size_t)k * F + k];
-            for (int p = tid; p < P; p += BLOCK) B[(size_t)k * P + p] /= dk;
+            for (int p = tid; p < P; p += NT) B[(size_t)k * P + p] /= dk;
             __syncthreads();
             const int m = F - k - 1;
-            for (int e = tid; e < m * P; e += BLOCK) {
+            for (int e = tid; e < m * P; e += NT) {
                 const int i = k + 1 + e / P, p = e % P;
                 B[(size_t)i * P + p] -= A[(size_t)i * F + k] * B[(size_t)k * P + p];
             }
@@ -537,9 +538,9 @@ __global__ __launch_bounds__(BLOCK) void normal_solve_kernel(const double *__res
         }
         for (int k = F - 1; k >= 0; --k) {
             const double dk = A[(size_t)k * F + k];
-            for (int p = tid; p < P; p += BLOCK) B[(size_t)k * P + p] /= dk;
+            for (int p = tid; p < P; p += NT) B[(size_t)k * P + p] /= dk;
             __syncthreads();
-            for (int e = tid; e < k * P; e += BLOCK) {
+            for (int e = tid; e < k * P; e += NT) {
                 const int i = e / P, p = e % P;
                 B[(size_t)i * P + p] -= A[(size_t)k * F + i] * B[(size_t)k * P + p];
             }
@@ -547,9 +548,9 @@ __global__ __launch_bounds__(BLOCK) void normal_solve_kernel(const double *__res
         }
     }
     const double qnan = __longlong_as_double(0x7ff8000000000000LL);
-    for (int e = tid; e < F * P; e += BLOCK) beta[e] = bad ? qnan : B[e];
+    for (int e = tid; e < F * P; e += NT) beta[e] = bad ? qnan : B[e];
     __syncthreads();
-    for (int p = tid; p < P; p += BLOCK) {
+    for (int p = tid; p < P; p += NT) {
         double icpt = 0.0;
         if (fit_intercept && !bad) {
             icpt = acc[(size_t)F * D + F + 1 + p] * inv_n;
@@ -698,7 +699,7 @@ extern "C" int wm_normal_solve_f64(const double *acc, int F, int P, int fit_inte
     hipStream_t st = (hipStream_t)stream;
     const size_t bytes = ((size_t)F * F + (size_t)F * P) * sizeof(double);
     if (bytes <= SOLVE_LDS_LIMIT) {
-        hipLaunchKernelGGL(normal_solve_kernel<true>, dim3(1), dim3(BLOCK), bytes + 16, st, acc, F, P,
+        hipLaunchKernelGGL(normal_solve_kernel<true>, dim3(1), dim3(F <= 24 ? 64 : BLOCK), bytes + 16, st, acc, F, P,
                            fit_intercept, ridge, beta, status, (double *)nullptr);
     } else {
         const size_t need = wm_normal_solve_workspace_bytes(F, P);
