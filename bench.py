@@ -32,6 +32,21 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: FP32 matrix 157.3 TFLOP/s
 
 
+def pmc_traffic(kernels, default_shape):
+    """HBM bytes per launch of `kernels` from the committed PMC passes (tools/pmc_bench.sh +
+    tools/pmc_summarise.py, FETCH_SIZE x2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes).  The
+    counters cannot be collected inside a timed run, so the figure is that of the committed profile
+    of this same command; it is only reported when the workload has the profiled (default) shape."""
+    if not default_shape:
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")) as fh:
+            table = json.load(fh)["kernels"]
+        return float(sum(table[k]["hbm_bytes"] for k in kernels))
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def dist_setup(ngpus):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -135,7 +150,9 @@ def run_gram(F, n_rows, steps, warmup, rank, world, cpu_base):
     if F * 0.5 < MFMA_F32_PEAK_TF * 1e3 / HBM_PEAK_GBS:   # arithmetic intensity F/2 flop/B vs ridge
         ach = bytes_per_row * n_rows / kavg / 1e9
         res["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                           "frac": ach / HBM_PEAK_GBS,
+                           "traffic": pmc_traffic(["gram_f16_kernel"],
+                                                  F == 16 and n_rows == 100_000_000),
                            "kernel": "gram_f16_kernel" if F == 16 else "gram_tile_kernel",
                            "algorithmic_bytes_per_row": bytes_per_row}
     else:
@@ -222,7 +239,9 @@ def run_conv(steps, warmup, rank, world, cpu_base, N=64, H=721, W=1440):
         "fwd_ms": fwd_ms, "bwd_wb_ms": bwd_ms,
         "roofline": {"bound": "hbm",
                      "achieved": (fwd_bytes + bwd_bytes) / ((fwd_ms + bwd_ms) * 1e-3) / 1e9,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "traffic": pmc_traffic(["conv_fwd_c1_kernel<3, 3>", "conv_bwd_wb_c1_kernel<3, 3>"],
+                                            (N, H, W) == (64, 721, 1440)),
                      "kernel": "conv_fwd_c1_kernel<3,3> + conv_bwd_wb_c1_kernel<3,3>",
                      "fwd_GBs": fwd_bytes / (fwd_ms * 1e-3) / 1e9,
                      "bwd_wb_GBs": bwd_bytes / (bwd_ms * 1e-3) / 1e9,
@@ -303,7 +322,8 @@ def run_model(steps, warmup, rank, world, cpu_base, B=721 * 1440):
            "config": {"workload": "newConvolution.CustomModel (1->16->32->32->32 conv stack + "
                                   "192->64->6 head) fwd+bwd+Adam, 1038240 grid points per GPU per step"},
            "roofline": {"bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF,
-                        "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF, "traffic": None,
+                        "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF,
+                        "traffic": pmc_traffic(["model_kernel<1>"], B == 721 * 1440),
                         "kernel": "model_kernel<1>", "algorithmic_flops_per_sample": flops}}
     if cpu_base and rank == 0 and world == 1:
         from oracle import model_ref
