@@ -226,10 +226,45 @@ def regression_goldens():
     np.savez_compressed(os.path.join(HERE, "regression_golden.npz"), **fix)
 
 
+def data_goldens():
+    """Outputs of the reference's data.py (imported with stubs for xarray and netCDF4, which it
+    only needs for file I/O) on a fake 5-file data set built by tests/fakes.py -- pins the pooled
+    mean/std arithmetic and the file-name clock, quirks included."""
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import fakes
+    for name in ("xarray", "netCDF4"):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+            sys.modules[name] = m
+    ref = import_reference("data")
+    ref.X_TRAIN_DATA_PATH = "/fake/wrfout"
+    n_files = 5
+    scale = {v: (-(k + 1.0), 2.0 * (k + 1)) for k, v in enumerate(ref.DATA_VARS)}
+    files = {ref.get_file_path(i, n_files): fakes.wrf_like_file(100 + i, ref.DATA_VARS,
+                                                                scale=scale)
+             for i in range(n_files)}
+    sys.modules["xarray"].open_dataset = fakes.FakeXarray(files).open_dataset
+    lo, hi = ref.calculate_data_range(n_files)
+    mean, std = ref.calculate_data_mean_std(n_files)
+    paths = {f"{i}/{n}": ref.get_file_path(i, n)
+             for n in (1, 13, 288, 289) for i in sorted({0, 1, 11, 12, n // 2, n - 1}) if i < n}
+    with open(os.path.join(HERE, "data_golden.json"), "w") as fh:
+        json.dump({"n_files": n_files, "seed0": 100, "shape": [1, 6, 7, 8],
+                   "data_path": "/fake/wrfout", "vars": ref.DATA_VARS,
+                   "scale": {k: list(v) for k, v in scale.items()},
+                   "min": lo, "max": hi, "mean": mean, "std": std, "paths": paths}, fh, indent=1)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "data":
+        data_goldens()
+        sys.exit(0)
     model_goldens()
     conv_goldens()
     regression_goldens()
+    data_goldens()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

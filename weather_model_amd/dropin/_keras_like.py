@@ -1,0 +1,385 @@
+"""The model object the regression drop-ins hand out in place of a ``keras.Model``.
+
+The reference builds ``[x1, x2] -> Flatten -> Concatenate -> Dense(linear) x k -> Dense`` and fits
+it with Adam on MSE (multipleRegression.py:273-298,341-350; singleRegression.py:74-96,500-509).
+Every layer is linear with a bias, so the stack spans exactly the affine maps R^{2p} -> R^p and the
+minimiser of its loss is ordinary least squares with an intercept.  ``LinearStackModel.fit``
+therefore consumes the same ``(x1, x2, y)`` batches, accumulates the Gram of ``[x1|x2|1|y]`` on the
+GPU (``wm_gram_f32``), solves the normal equations once (``wm_normal_solve_f64``) and reports the
+loss/metrics of that exact minimiser; ``predict`` is ``wm_linear_predict_f32``.
+
+What a caller of the reference sees unchanged: ``compile(...)``, ``fit(dataset, epochs=,
+steps_per_epoch=, validation_data=, validation_steps=, batch_size=, callbacks=, verbose=)`` ->
+object with ``.history`` (dict of lists) and ``.epoch`` (list), ``predict([x1, x2])`` -> float32
+ndarray ``(B, prod(input_shape))``, ``evaluate``, ``save``/``export``, ``get_weights`` (the Keras
+variable order: kernel, bias per Dense layer).  What differs: one pass over ``steps_per_epoch``
+batches is the whole fit (the solve is exact, so ``epoch == [0]`` whatever ``epochs`` says -- the
+reference's EarlyStopping(patience=2) would have nothing left to improve), and there is no CPU
+path: without libwm.so and a GPU every compute call raises.
+
+Parity note: tensorflow/keras are absent from the build container, so nothing here is pinned
+against the reference's own training run ("parity unpinned"); the fit is pinned against float64
+``numpy.linalg.lstsq`` on the same rows (tests/test_gpu_regression_dropin.py).
+"""
+from __future__ import annotations
+
+import json
+import os
+from math import prod
+
+import numpy as np
+import torch
+
+from weather_model_amd import dp, ops
+
+_MSLE_EPS = 1e-7          # keras.backend.epsilon(), the clip of mean_squared_logarithmic_error
+
+
+class History:
+    """Stand-in for ``keras.callbacks.History``: ``.history`` and ``.epoch`` are what the reference
+    reads (multipleRegression.py:559-560, singleRegression.py:559)."""
+
+    def __init__(self, model=None):
+        self.model = model
+        self.history: dict[str, list[float]] = {}
+        self.epoch: list[int] = []
+        self.params: dict = {}
+
+    def __repr__(self):
+        return f"History(epoch={self.epoch}, history={self.history})"
+
+
+class EarlyStopping:
+    """Accepted for call compatibility (``tf.keras.callbacks.EarlyStopping(monitor='loss',
+    patience=2)``, multipleRegression.py:339); the exact solve leaves it nothing to do."""
+
+    def __init__(self, monitor="val_loss", patience=0, **kwargs):
+        self.monitor, self.patience, self.kwargs = monitor, patience, kwargs
+
+
+def _metric_names(metrics):
+    names = []
+    for m in metrics or []:
+        n = m if isinstance(m, str) else getattr(m, "__name__", getattr(m, "name", str(m)))
+        n = {"mean_absolute_error": "mae", "mean_squared_logarithmic_error": "msle",
+             "mse": "mean_squared_error"}.get(n, n)
+        if n not in ("mae", "msle", "mean_squared_error"):
+            raise ValueError(f"unsupported metric {n!r} (have mae, msle, mean_squared_error)")
+        if n not in names:
+            names.append(n)
+    return names
+
+
+def _as_rows(x1, x2, y):
+    """One reference batch -> (X (B,2p) float32, Y (B,p) float32) host arrays."""
+    a = np.asarray(x1, dtype=np.float32)
+    b = np.asarray(x2, dtype=np.float32)
+    t = np.asarray(y, dtype=np.float32)
+    if a.shape != b.shape:
+        raise ValueError(f"x1 {a.shape} and x2 {b.shape} differ")
+    B = a.shape[0]
+    if t.shape[0] != B:
+        raise ValueError(f"y has {t.shape[0]} rows, x has {B}")
+    return np.concatenate((a.reshape(B, -1), b.reshape(B, -1)), axis=1), t.reshape(B, -1)
+
+
+def _batches(source, steps):
+    """Iterate the (x1, x2, y) batches of a reference-style data source: a callable returning a
+    generator (WeatherDataGenerator / WeatherGenerator, which the reference wraps with
+    tf.data.Dataset.from_generator), a plain iterator, a Sequence (``len`` + ``[i]``), or one
+    ``(x1, x2, y)`` tuple of arrays."""
+    if isinstance(source, (tuple, list)) and len(source) == 3 and not callable(source[0]):
+        yield source
+        return
+    if hasattr(source, "__len__") and hasattr(source, "__getitem__") and not callable(source):
+        n = len(source) if steps is None else min(steps, len(source))
+        for i in range(n):
+            yield source[i]
+        return
+    it = source() if callable(source) else iter(source)
+    if steps is None:
+        raise ValueError("steps_per_epoch / validation_steps is required for a generator source "
+                         "(the reference's generators never end)")
+    for _ in range(int(steps)):
+        try:
+            yield next(it)
+        except StopIteration:
+            return
+
+
+class _RowStore:
+    """Rows staged through one pinned host buffer into resident device chunks."""
+
+    def __init__(self, F, P, device, chunk_rows):
+        self.F, self.P, self.device = F, P, device
+        self.chunk_rows = int(chunk_rows)
+        self.host = torch.empty((self.chunk_rows, F + P), dtype=torch.float32,
+                                pin_memory=torch.cuda.is_available())
+        self.fill = 0
+        self.chunks: list[tuple[torch.Tensor, torch.Tensor]] = []
+        self.rows = 0
+
+    def add(self, X, Y):
+        if X.shape[1] != self.F or Y.shape[1] != self.P:
+            raise ValueError(f"batch is ({X.shape[1]} -> {Y.shape[1]}), model is "
+                             f"({self.F} -> {self.P})")
+        pos, B = 0, X.shape[0]
+        while pos < B:
+            m = min(B - pos, self.chunk_rows - self.fill)
+            dst = self.host[self.fill:self.fill + m]
+            dst[:, :self.F] = torch.from_numpy(X[pos:pos + m])
+            dst[:, self.F:] = torch.from_numpy(Y[pos:pos + m])
+            self.fill += m
+            pos += m
+            if self.fill == self.chunk_rows:
+                self.flush()
+
+    def flush(self):
+        if self.fill == 0:
+            return
+        dev = self.host[:self.fill].to(self.device, non_blocking=True)
+        X = dev[:, :self.F].contiguous()
+        Y = dev[:, self.F:].contiguous()
+        torch.cuda.current_stream(self.device).synchronize()     # host buffer is reused next
+        self.chunks.append((X, Y))
+        self.rows += self.fill
+        self.fill = 0
+
+
+class LinearStackModel:
+    """``create_model`` / ``createModel`` of the regression scripts, as one affine map."""
+
+    def __init__(self, input_shape, hidden_layers=("layer1", "layer2"), output_name="output",
+                 device=None):
+        self.input_shape = tuple(int(v) for v in input_shape)
+        self.p = prod(self.input_shape)
+        self.F, self.P = 2 * self.p, self.p
+        self.layer_names = tuple(hidden_layers) + (output_name,)
+        self.device = torch.device(device if device is not None else "cuda")
+        self.beta = None            # (F+1, P) float64 device tensor, intercept last
+        self.ridge = 0.0
+        self.compiled = False
+        self.metrics_names: list[str] = ["loss"]
+        self._metric_keys: list[str] = []
+        self.optimizer = None
+        self.loss = None
+        self.stop_training = False
+        self.rows_seen = 0
+
+    # ------------------------------------------------------------------ keras surface
+    def compile(self, optimizer="adam", loss=None, metrics=None, weighted_metrics=None, **kwargs):
+        """Records the configuration.  The optimizer is irrelevant to the result (the fit goes to
+        the minimiser Adam/SGD converge to); only mean-squared-error loss is meaningful."""
+        name = loss if isinstance(loss, str) else getattr(loss, "__name__", None)
+        if loss is not None and name not in ("mean_squared_error", "mse", "MSE", None):
+            raise ValueError(f"only the mean-squared-error loss has a closed form (got {name!r})")
+        self.optimizer, self.loss = optimizer, loss
+        self._metric_keys = _metric_names(list(metrics or []) + list(weighted_metrics or []))
+        self.metrics_names = ["loss"] + self._metric_keys
+        self.compiled = True
+        return None
+
+    def _need_beta(self):
+        if self.beta is None:
+            # an unfitted keras model predicts from its random initial weights; ours from zeros
+            self.beta = torch.zeros((self.F + 1, self.P), device=self.device, dtype=torch.float64)
+        return self.beta
+
+    def _device_rows(self, x1, x2):
+        if isinstance(x1, torch.Tensor):
+            a = x1.to(self.device, torch.float32)
+            b = x2.to(self.device, torch.float32)
+            return torch.cat((a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1)), 1).contiguous()
+        a = np.asarray(x1, dtype=np.float32)
+        b = np.asarray(x2, dtype=np.float32)
+        X = np.concatenate((a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1)), axis=1)
+        return torch.from_numpy(np.ascontiguousarray(X)).to(self.device)
+
+    def __call__(self, inputs, training=False):
+        x1, x2 = inputs
+        X = self._device_rows(x1, x2)
+        if X.shape[1] != self.F:
+            raise ValueError(f"inputs flatten to {X.shape[1]} columns, model takes {self.F}")
+        return ops.linear_predict(X, self._need_beta())
+
+    def predict(self, x, batch_size=None, verbose=0, steps=None, **kwargs):
+        """``model.predict([data1, data2])`` -> float32 ndarray (B, prod(input_shape))
+        (multipleRegression.py:451, singleRegression.py:579)."""
+        return self(x).cpu().numpy()
+
+    # ------------------------------------------------------------------ fit
+    def _metrics(self, chunks, prefix=""):
+        """loss + compiled metrics of the current beta over resident row chunks."""
+        keys = ["loss"] + self._metric_keys
+        sums = {k: torch.zeros((), device=self.device, dtype=torch.float64) for k in keys}
+        count = 0
+        for X, Y in chunks:
+            pred = ops.linear_predict(X, self.beta).double()
+            y = Y.double()
+            d = pred - y
+            sums["loss"] += (d * d).sum()
+            if "mean_squared_error" in sums:
+                sums["mean_squared_error"] += (d * d).sum()
+            if "mae" in sums:
+                sums["mae"] += d.abs().sum()
+            if "msle" in sums:
+                e = torch.log1p(pred.clamp_min(_MSLE_EPS)) - torch.log1p(y.clamp_min(_MSLE_EPS))
+                sums["msle"] += (e * e).sum()
+            count += Y.numel()
+        tot = torch.stack([sums[k] for k in keys])
+        cnt = torch.tensor([float(count)], device=self.device, dtype=torch.float64)
+        if dp.world() > 1:
+            both = torch.cat((tot, cnt))
+            dp.allreduce_sum_(both)
+            tot, cnt = both[:-1], both[-1:]
+        vals = (tot / cnt.clamp_min(1.0)).cpu().tolist()
+        return {prefix + k: float(v) for k, v in zip(keys, vals)}
+
+    def fit(self, x=None, y=None, batch_size=None, epochs=1, verbose=1, callbacks=None,
+            validation_split=0.0, validation_data=None, shuffle=True, steps_per_epoch=None,
+            validation_steps=None, chunk_rows=1 << 18, ridge=None, **kwargs):
+        """Least-squares fit over ``steps_per_epoch`` batches of ``x`` (see module docstring).
+
+        ``x`` is any source ``_batches`` understands; ``(x, y)`` arrays are also accepted with
+        ``x = [x1, x2]``.  Under an initialised ``torch.distributed`` group every rank feeds its own
+        batches and the partial Grams are summed by one all-reduce."""
+        if y is not None:
+            x1, x2 = x
+            source = (x1, x2, y)
+        else:
+            source = x
+        store = _RowStore(self.F, self.P, self.device, chunk_rows)
+        for batch in _batches(source, steps_per_epoch):
+            store.add(*_as_rows(*batch))
+        store.flush()
+        D = self.F + 1 + self.P
+        acc = torch.zeros((D, D), device=self.device, dtype=torch.float64)
+        for X, Y in store.chunks:
+            ops.gram(X, Y, acc)
+        dp.reduce_gram_(acc)
+        n_total = float(acc[self.F, self.F].item())            # sum of 1*1 = global row count
+        if n_total < 1:
+            raise ValueError("fit received no rows")
+        self.rows_seen = int(n_total)
+        self.beta, self.ridge = self._solve(acc, ridge)
+        hist = History(self)
+        hist.params = {"epochs": epochs, "steps": steps_per_epoch, "verbose": verbose}
+        logs = self._metrics(store.chunks)
+        if validation_data is not None:
+            vstore = _RowStore(self.F, self.P, self.device, chunk_rows)
+            for batch in _batches(validation_data, validation_steps):
+                vstore.add(*_as_rows(*batch))
+            vstore.flush()
+            logs.update(self._metrics(vstore.chunks, prefix="val_"))
+        for k, v in logs.items():
+            hist.history[k] = [v]
+        hist.epoch = [0]
+        if verbose and dp.rank() == 0:
+            shown = " - ".join(f"{k}: {v:.6g}" for k, v in logs.items())
+            print(f"Epoch 1/{epochs} (closed-form least squares over {self.rows_seen} rows)\n"
+                  f"{steps_per_epoch if steps_per_epoch is not None else '?'} steps - {shown}")
+        self.history = hist
+        return hist
+
+    def _solve(self, acc, ridge):
+        """Normal-equation solve; if the centred X'X is not numerically positive definite (the
+        6x6x6 cubes of singleRegression are strongly collinear) retry with a small ridge relative
+        to the mean diagonal, growing tenfold, and report the value used."""
+        F, P = self.F, self.P
+        if ridge is not None:
+            return ops.normal_solve(acc, F, P, True, float(ridge)), float(ridge)
+        try:
+            return ops.normal_solve(acc, F, P, True, 0.0), 0.0
+        except RuntimeError:
+            pass
+        n = acc[F, F]
+        diag = torch.diagonal(acc)[:F] - acc[F, :F] ** 2 / n      # centred sums of squares
+        scale = float(diag.clamp_min(0).mean().item())
+        scale = scale if scale > 0 else 1.0
+        r = 1e-12 * scale
+        while r <= 1e-2 * scale:
+            try:
+                return ops.normal_solve(acc, F, P, True, r), r
+            except RuntimeError:
+                r *= 10.0
+        raise RuntimeError("normal equations stayed singular up to ridge = 1e-2 * mean variance")
+
+    def evaluate(self, x=None, y=None, batch_size=None, verbose=0, steps=None, **kwargs):
+        """[loss, *metrics] of the current map over a data source (model.py:88 style)."""
+        self._need_beta()
+        source = (x[0], x[1], y) if y is not None else x
+        store = _RowStore(self.F, self.P, self.device, 1 << 16)
+        for batch in _batches(source, steps):
+            store.add(*_as_rows(*batch))
+        store.flush()
+        logs = self._metrics(store.chunks)
+        out = [logs[k] for k in ["loss"] + self._metric_keys]
+        return out if len(out) > 1 else out[0]
+
+    # ------------------------------------------------------------------ weights / persistence
+    @property
+    def coefficients(self):
+        """(kernel (2p, p), bias (p,)) float64 ndarrays of the fitted affine map."""
+        b = self._need_beta().cpu().numpy()
+        return b[:self.F].copy(), b[self.F].copy()
+
+    def get_weights(self):
+        """Keras variable order [kernel, bias] per Dense layer; the hidden square layers carry the
+        identity so the stack composes to the fitted map (one of its infinitely many equivalent
+        factorisations)."""
+        K, c = self.coefficients
+        out = []
+        for _ in self.layer_names[:-1]:
+            out += [np.eye(self.F, dtype=np.float32), np.zeros((self.F,), np.float32)]
+        return out + [K.astype(np.float32), c.astype(np.float32)]
+
+    def set_weights(self, weights):
+        """Accepts the Keras list and stores the composite affine map it spans."""
+        if len(weights) != 2 * len(self.layer_names):
+            raise ValueError(f"expected {2 * len(self.layer_names)} arrays")
+        A = np.eye(self.F, dtype=np.float64)
+        c = np.zeros((self.F,), np.float64)
+        for i in range(len(self.layer_names)):
+            W = np.asarray(weights[2 * i], np.float64)
+            b = np.asarray(weights[2 * i + 1], np.float64)
+            A = A @ W
+            c = c @ W + b
+        if A.shape != (self.F, self.P):
+            raise ValueError(f"weights compose to {A.shape}, model is {(self.F, self.P)}")
+        beta = np.concatenate((A, c[None, :]), axis=0)
+        self.beta = torch.from_numpy(beta).to(self.device)
+
+    @property
+    def trainable_variables(self):
+        return self.get_weights()
+
+    def count_params(self):
+        return sum(int(w.size) for w in self.get_weights())
+
+    def summary(self, print_fn=print):
+        print_fn(f"LinearStackModel: inputs 2 x {self.input_shape} -> Dense layers "
+                 f"{self.layer_names} -> {self.P}; {self.count_params()} parameters; "
+                 f"fitted={'yes' if self.beta is not None else 'no'}")
+
+    def save(self, path, **kwargs):
+        """``model.save(...)`` (singleRegression.py:616): the affine map as .npz + a JSON config
+        (not a .keras archive -- there is no keras here)."""
+        K, c = self.coefficients
+        base = str(path)
+        if os.path.isdir(base):
+            base = os.path.join(base, "linear_stack_model")
+        np.savez(base if base.endswith(".npz") else base + ".npz", kernel=K, bias=c,
+                 config=json.dumps({"input_shape": self.input_shape,
+                                    "layers": self.layer_names, "ridge": self.ridge}))
+
+    export = save           # ``mod.export(...)`` (multipleRegression.py:585)
+
+    @classmethod
+    def load(cls, path, device=None):
+        z = np.load(path, allow_pickle=False)
+        cfg = json.loads(str(z["config"]))
+        m = cls(tuple(cfg["input_shape"]), tuple(cfg["layers"][:-1]), cfg["layers"][-1], device)
+        beta = np.concatenate((z["kernel"], z["bias"][None, :]), axis=0)
+        m.beta = torch.from_numpy(beta).to(m.device)
+        m.ridge = cfg.get("ridge", 0.0)
+        return m

@@ -1,0 +1,360 @@
+"""Drop-in mirror of the reference's ``singleRegression.py``.
+
+Same public names and call shapes as /root/reference/singleRegression.py; the Keras stack
+``Dense(2p, linear) -> Dense(p)`` (:74-85) fitted by Adam (:87-96,500-509) becomes the GPU
+least-squares path behind ``createModel(...).fit`` (``_keras_like.LinearStackModel``).
+
+Differences on purpose:
+* importing this module touches no file: the reference lists and opens the data directory at
+  import (``DIM``/``DS_DIM``/``DATA_RANGE``, :116,125,142).  Here those three globals are computed
+  on first attribute access (module ``__getattr__``) and cached.
+* ``xarray`` is imported on first use; tests assign the module attribute ``xr``.
+* ``tf.distribute.MirroredStrategy`` (:491-496) has no counterpart: multi-GPU is one process per
+  GPU, each feeding its own batches, with one all-reduce of the Gram inside ``fit``.
+Kept, and named: the normaliser is inverted -- ``NORMALIZE_DATA = True`` returns the RAW field
+(:324-328,443-447); ``getGlobalRange`` seeds both min and max with 0 (:129-130).
+"""
+from __future__ import annotations
+
+import fnmatch
+import os
+from math import prod
+
+import numpy as np
+
+from ._keras_like import EarlyStopping, History, LinearStackModel  # noqa: F401
+
+XTRAIN_DATA_PATH = 'D:/Documents/Code/research/wrfout'
+YTRAIN_DATA_PATH = 'D:/Documents/Code/research/wrfout'
+DATA_VAR = 'T'
+BATCH_SIZE = 4
+STEPS_PER_EPOCH = int(1000 / 32)
+EPOCHS = 10
+VALIDATION_SPLIT = 0.2
+VALIDATION_STEP = 5
+LEARNING_RATE = 0.001
+SAVE_MODEL = False
+KERAS_MODELS_PATH = 'D:/Documents/Code/research/keras-models'
+NORMALIZE_DATA = True
+CUBE_SIZE = 6
+
+xr = None     # the xarray module, imported on first use (tests assign a stand-in)
+_lazy: dict = {}
+
+
+def _xr():
+    global xr
+    if xr is None:
+        import xarray
+        xr = xarray
+    return xr
+
+
+def __getattr__(name):
+    """DIM, DS_DIM, DATA_RANGE: computed when first read, not at import (:116,125,142)."""
+    makers = {"DIM": getInputDim, "DS_DIM": getDataDim, "DATA_RANGE": getGlobalRange}
+    if name in makers:
+        if name not in _lazy:
+            _lazy[name] = makers[name]()
+        return _lazy[name]
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
+
+
+class CustomModel(LinearStackModel):
+    """Counterpart of the reference's ``keras.Model`` subclass (:36-71)."""
+
+
+def createModel(inputShape):
+    """input1/input2 -> Flatten -> Concatenate -> Dense(2p, linear) 'layer1' -> Dense(p) 'output'
+    (:74-85)."""
+    return CustomModel(inputShape, hidden_layers=("layer1",), output_name="output")
+
+
+def createCompiledModel(inputDim):
+    model = createModel(inputDim)
+    model.compile(optimizer=("adam", LEARNING_RATE), loss='mean_squared_error',
+                  metrics=['mean_squared_error'])
+    return model                                                            # :87-96
+
+
+def getFilePath(index, dim):
+    """5-minute clock file name; the last file rolls over to the next day at 00 (:99-107)."""
+    last = index == (dim[0] - 1)
+    minute = str((index % 12) * 5).zfill(2)
+    hour = '00' if last else str(index // 12).zfill(2)
+    return f"{XTRAIN_DATA_PATH}/wrfout_d02_2023-06-2{'1' if last else '0'}_{hour}%3A{minute}%3A00"
+
+
+def getInputDim():
+    fileCount = len(fnmatch.filter(os.listdir(XTRAIN_DATA_PATH), '*'))
+    return (fileCount, CUBE_SIZE, CUBE_SIZE, CUBE_SIZE)                     # :109-115
+
+
+def getDataDim():
+    ds = _xr().open_dataset(f'{XTRAIN_DATA_PATH}/wrfout_d02_2023-06-20_00%3A00%3A00')
+    dim = ds[DATA_VAR].shape
+    ds.close()
+    return (dim[0], dim[1] // 5, dim[2] // 10, dim[3] // 10)                # :118-124
+
+
+def getGlobalRange():
+    """(min, max) of DATA_VAR over all files, both seeded with 0 as in the reference (:127-141)."""
+    dim = getInputDim()
+    maxValue = 0
+    minValue = 0
+    for i in range(dim[0]):
+        ds = _xr().open_dataset(getFilePath(i, dim))
+        maxValue = max(maxValue, float(ds[DATA_VAR].max()))
+        minValue = min(minValue, float(ds[DATA_VAR].min()))
+        ds.close()
+    return (minValue, maxValue)
+
+
+def getData():
+    """Whole-file arrays scaled by their maxima (:145-164)."""
+    dsX = _xr().open_dataset(XTRAIN_DATA_PATH)
+    dsY = _xr().open_dataset(YTRAIN_DATA_PATH)
+    dataX = dsX[DATA_VAR].to_numpy()
+    dataY = dsY[DATA_VAR].to_numpy()
+    dataY = dataY.reshape(dataY.shape[0], dataY.shape[1] * dataY.shape[2])
+    return dataX / np.amax(dataX), dataY / np.amax(dataY)
+
+
+class WeatherSequence:
+    """``keras.utils.Sequence``-style source over one file's leading axis (:168-207): batch i is
+    (rows [i*b, (i+1)*b), the same rows shifted by one, the y rows flattened), each divided by its
+    own maximum."""
+
+    def __init__(self, xFilename, yFilename, dataVar, batchSize):
+        self.xFilename = xFilename
+        self.yFilename = yFilename
+        self.dataVar = dataVar
+        self.batchSize = batchSize
+        ds = _xr().open_dataset(self.xFilename)
+        self.dataLength = ds[self.dataVar].shape[0]
+        self.length = int(np.floor(self.dataLength / float(self.batchSize)))
+        ds.close()
+
+    def __len__(self):
+        return self.length
+
+    def __getitem__(self, index):
+        lo, hi = index * self.batchSize, (index + 1) * self.batchSize
+        dsX = _xr().open_dataset(self.xFilename)
+        data = dsX[self.dataVar]
+        batchStartX = data[lo:hi].to_numpy()
+        batchEndX = data[lo + 1:hi + 1].to_numpy()
+        batchStartX = batchStartX / np.amax(batchStartX)
+        batchEndX = batchEndX / np.amax(batchEndX)
+        dsY = _xr().open_dataset(self.yFilename)
+        batchY = dsY[self.dataVar][lo:hi].to_numpy()
+        batchY = batchY / np.amax(batchY)
+        batchY = batchY.reshape(batchY.shape[0], batchY.shape[1] * batchY.shape[2])
+        dsX.close()
+        dsY.close()
+        return batchStartX, batchEndX, batchY
+
+    def getValidationData(self):
+        pass
+
+
+def optimizeDataset():
+    """The reference subclasses ``tf.data.Dataset`` only to wrap a WeatherGenerator built from the
+    module globals (:209-222); the generator itself is what ``fit`` consumes here."""
+    import sys
+    mod = sys.modules[__name__]
+    return WeatherGenerator(XTRAIN_DATA_PATH, YTRAIN_DATA_PATH, DATA_VAR, BATCH_SIZE, EPOCHS,
+                            VALIDATION_SPLIT, mod.DIM, mod.DS_DIM, mod.DATA_RANGE)
+
+
+def _cube(path, dataVar, region, scale):
+    ds = _xr().open_dataset(path)
+    data = ds[dataVar][0][region[0]: region[0] + CUBE_SIZE,
+                          region[1]: region[1] + CUBE_SIZE,
+                          region[2]: region[2] + CUBE_SIZE]
+    out = np.array(scale(data))
+    ds.close()
+    return out
+
+
+class WeatherGenerator:
+    """Yields (x1, x2, y) = the CUBE_SIZE^3 cube of DATA_VAR at files i, i+2, i+1 for batchSize
+    consecutive i, walking the regions of the grid (:226-340)."""
+
+    def __init__(self, xFilename, yFilename, dataVar, batchSize, epochs, validationSplit, dim,
+                 dsDim, dataRange):
+        self.xFilename = xFilename
+        self.yFilename = yFilename
+        self.dataVar = dataVar
+        self.batchSize = batchSize
+        self.epochs = epochs
+        self.validationSplit = validationSplit
+        self.dim = dim
+        self.dsDim = dsDim
+        self.dataRange = dataRange
+        self.length = int(np.floor((self.dim[0] * (1 - self.validationSplit)) / self.batchSize)) - 1
+        self.startIndex = int(self.dim[0] * validationSplit)
+        self.trainOnX = True
+        self.index = 0
+        self.regionIndex = (0, 0, 0)
+
+    def __len__(self):
+        return self.length
+
+    def _gather(self, files, offset, region, what):
+        cubes = []
+        for i in files:
+            try:
+                cubes.append(_cube(getFilePath(i + offset, self.dim), self.dataVar, region,
+                                   self.normalizeData))
+            except Exception as e:
+                raise Exception(f"{i} {what} error: {e}")
+        return np.stack(cubes)
+
+    def __getitem__(self, index, regionIndex):
+        first = self.startIndex + index * self.batchSize
+        files = range(first, first + self.batchSize)
+        x1 = self._gather(files, 0, regionIndex, "BatchX1Data")
+        x2 = self._gather(files, 2, regionIndex, "BatchX2Data")
+        y = self._gather(files, 1, regionIndex, "BatchYData")
+        return x1, x2, y.reshape(y.shape[0], prod(y.shape[1:]))
+
+    def normalizeData(self, data):
+        """Inverted on purpose, as in the reference (:324-328): NORMALIZE_DATA=True -> raw data."""
+        data = data.to_numpy()
+        if NORMALIZE_DATA:
+            return data
+        return (data - self.dataRange[0]) / (self.dataRange[1] - self.dataRange[0])
+
+    def __call__(self):
+        while True:
+            region = (self.regionIndex[0] % self.dsDim[1],
+                      self.regionIndex[1] % self.dsDim[2],
+                      self.regionIndex[2] % self.dsDim[3])
+            yield self.__getitem__(self.index % self.__len__(), region)
+            self.index += 1
+            self.regionIndex = (self.index // self.__len__(),
+                                self.regionIndex[0] // self.dsDim[1],
+                                self.regionIndex[1] // self.dsDim[2])
+
+
+class ValidationData:
+    """Corner-cube batches of the first validationSplit of the files (:344-447).  ``dsDim`` and
+    ``dataRange`` default to None because the reference's own call site omits them (:524)."""
+
+    def __init__(self, xFilename, yFilename, dataVar, validationSplit, validationSteps, batchSize,
+                 dim, dsDim=None, dataRange=None):
+        self.xFilename = xFilename
+        self.yFilename = yFilename
+        self.dataVar = dataVar
+        self.validationSplit = validationSplit
+        self.validationSteps = validationSteps
+        self.batchSize = batchSize
+        self.dim = dim
+        self.dsDim = dsDim
+        self.dataRange = dataRange
+        self.startIndex = int(self.dim[0] * validationSplit)
+        self.index = 0
+
+    def __getitem__(self, index):
+        return self.getValidationData(index)
+
+    def __len__(self):
+        return self.validationSteps
+
+    def __call__(self):
+        while True:
+            yield self.__getitem__(self.index % self.__len__())
+            self.index += 1
+
+    def getValidationData(self, index):
+        files = range(index * self.batchSize, (index + 1) * self.batchSize)
+        out = []
+        for offset, what in ((0, "BatchX1Data"), (2, "BatchX2Data"), (1, "BatchYData")):
+            cubes = []
+            for i in files:
+                try:
+                    cubes.append(_cube(getFilePath(i + offset, self.dim), self.dataVar, (0, 0, 0),
+                                       self.normalizeData))
+                except Exception as e:
+                    raise Exception(f"{i} Validation {what}: {e}")
+            out.append(np.stack(cubes))
+        x1, x2, y = out
+        return x1, x2, y.reshape(y.shape[0], prod(y.shape[1:]))
+
+    def normalizeData(self, data):
+        data = data.to_numpy()
+        if NORMALIZE_DATA:
+            return data
+        return (data - self.dataRange[0]) / (self.dataRange[1] - self.dataRange[0])
+
+
+def fitModelWithGenerator():
+    """(history, model) fitted on the region-walking generator (:450-511)."""
+    dim = getInputDim()
+    dsDim = getDataDim()
+    dataRange = getGlobalRange()
+    steps = int(((np.floor((dim[0] * (1 - VALIDATION_SPLIT)) / BATCH_SIZE)) - 1)
+                * (dsDim[1] // CUBE_SIZE) * (dsDim[2] // CUBE_SIZE) * (dsDim[3] // CUBE_SIZE))
+    dataset = WeatherGenerator(XTRAIN_DATA_PATH, YTRAIN_DATA_PATH, DATA_VAR, BATCH_SIZE, EPOCHS,
+                               VALIDATION_SPLIT, dim, dsDim, dataRange)
+    model = createCompiledModel(dim[1:])
+    callback = EarlyStopping(monitor='loss', patience=2)
+    history = model.fit(dataset, batch_size=BATCH_SIZE, steps_per_epoch=steps, epochs=EPOCHS,
+                        callbacks=[callback], verbose=1)
+    return history, model
+
+
+def fitModelWithSequence():
+    """(history, model) fitted on a WeatherSequence, validated on the first validation batch
+    (:517-538)."""
+    dim = getInputDim()
+    sequence = WeatherSequence(XTRAIN_DATA_PATH, YTRAIN_DATA_PATH, DATA_VAR, BATCH_SIZE)
+    validationData = ValidationData(XTRAIN_DATA_PATH, YTRAIN_DATA_PATH, DATA_VAR,
+                                    VALIDATION_SPLIT, VALIDATION_STEP, BATCH_SIZE, dim)
+    model = createCompiledModel(dim[1:])
+    callback = EarlyStopping(monitor='loss', patience=2)
+    history = model.fit(sequence, epochs=EPOCHS,
+                        validation_data=validationData.getValidationData(0),
+                        callbacks=[callback], verbose=1)
+    return history, model
+
+
+def main():
+    """Fit, then compare the model's and the two-frame average's error on the first cube
+    (:556-616)."""
+    history, model = fitModelWithGenerator()
+    print(history.history)
+    dataRange = getGlobalRange()
+
+    def corner(stamp):
+        ds = _xr().open_dataset(f'{XTRAIN_DATA_PATH}/wrfout_d02_2023-06-20_{stamp}')
+        cube = ds[DATA_VAR][0][:CUBE_SIZE, :CUBE_SIZE, :CUBE_SIZE].to_numpy()
+        ds.close()
+        if NORMALIZE_DATA:
+            cube = (cube - dataRange[0]) / (dataRange[1] - dataRange[0])
+        return cube
+
+    data1 = np.expand_dims(corner('00%3A00%3A00'), axis=0)
+    data2 = np.expand_dims(corner('00%3A10%3A00'), axis=0)
+    dataY = corner('00%3A05%3A00')
+    prediction = model.predict([data1, data2]).reshape(CUBE_SIZE, CUBE_SIZE, CUBE_SIZE)
+    average = (data1 + data2) / 2
+    average_error = abs(dataY - average)
+    prediction_error = abs(dataY - prediction)
+    print("###########Errors##########")
+    print(average_error)
+    print(prediction_error)
+    print("###########Stats###########")
+    print(f"Average summed error: {np.sum(average_error)}")
+    print(f"Prediction summed error: {np.sum(prediction_error)}")
+    print(f"Average (max, min) error: {np.max(average_error), np.min(average_error)}")
+    print(f"Prediction (max, min) error: {np.max(prediction_error), np.min(prediction_error)}")
+    print(f"Average mean error: {np.mean(average_error)}")
+    print(f"Prediction mean error: {np.mean(prediction_error)}")
+    if SAVE_MODEL:
+        model.save(f'{KERAS_MODELS_PATH}/weatherModel.keras')
+
+
+if __name__ == '__main__':
+    main()
