@@ -141,8 +141,8 @@ def test_single_regression_p216_collinear_cubes():
 
 
 def test_fit_streams_many_chunks():
-    """Rows cross several staging chunks; the result equals a one-chunk fit bit for bit in the
-    Gram (float64 combine in a fixed order per chunk) up to summation order across chunks."""
+    """Rows cross several staging chunks; the result equals a one-chunk fit up to the float32
+    grouping of the partial sums (products summed in float32 over <= 1024 rows, then float64)."""
     from weather_model_amd.dropin._keras_like import LinearStackModel
     rng = np.random.default_rng(9)
     n = 50_000
@@ -159,7 +159,7 @@ def test_fit_streams_many_chunks():
     b.fit((x1, x2, y), verbose=0)
     Ka, ca = a.coefficients
     Kb, cb = b.coefficients
-    np.testing.assert_allclose(Ka, Kb, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(Ka, Kb, rtol=0, atol=5e-6)
     beta = _lstsq(np.concatenate([x1, x2], 1), y)
     assert np.abs(np.concatenate([Kb, cb[None]]) - beta).max() / np.abs(beta).max() < 1e-4
     assert torch.cuda.is_available()
