@@ -71,6 +71,40 @@ int wm_conv2d_bwd_wb_f32(const float *x, const float *gy, float *gw, float *gb,
                          int N, int Cin, int H, int W, int Cout, int kH, int kW,
                          void *stream);
 
+/* 3-D counterpart: replaces keras.layers.Conv3D(filters, kernel_size, strides=1, padding='valid',
+ * data_format='channels_first') forward (convolution.py:164,166,170,172) and, reached from
+ * CustomModel.train_step's tape.gradient (convolution.py:49-54), its three gradients.
+ *   y[b,o,i,j,l] = bias[o] + sum_{c,kd,kh,kw} w[o,c,kd,kh,kw] x[b,c,i+kd,j+kh,l+kw]
+ * x is (B,Cin,D,H,W), w is (Cout,Cin,kD,kH,kW) (PyTorch order; a Keras kernel (kD,kH,kW,Cin,Cout)
+ * is its permutation (4,3,0,1,2)), y is (B,Cout,D-kD+1,H-kH+1,W-kW+1).  Implemented for at most 64
+ * channels on either side and tensors below 2^31 elements (WM_ERR_UNSUPPORTED otherwise).
+ * Gradients: gx = sum_{o,k} w gy (full correlation), gw = sum_{b,pos} gy x, gb = sum gy; the
+ * weight/bias sums go through float64 partials in `workspace`, combined in a fixed order. */
+int wm_conv3d_fwd_f32(const float *x, const float *w, const float *b, float *y,
+                      int B, int Cin, int D, int H, int W, int Cout, int kD, int kH, int kW,
+                      int relu, void *stream);
+int wm_conv3d_bwd_data_f32(const float *gy, const float *w, float *gx,
+                           int B, int Cin, int D, int H, int W, int Cout, int kD, int kH, int kW,
+                           void *stream);
+size_t wm_conv3d_bwd_wb_workspace_bytes(int B, int Cin, int D, int H, int W, int Cout,
+                                        int kD, int kH, int kW);
+int wm_conv3d_bwd_wb_f32(const float *x, const float *gy, float *gw, float *gb,
+                         void *workspace, size_t workspace_bytes,
+                         int B, int Cin, int D, int H, int W, int Cout, int kD, int kH, int kW,
+                         void *stream);
+
+/* Replaces keras.layers.MaxPool3D(pool_size=2, strides=2) (convolution.py:165,167,171,173) and its
+ * gradient.  x is (B,A1,A2,A3,C) contiguous and the window runs over A1,A2,A3 ("channels_last",
+ * the Keras default the reference leaves in place although its convs are channels_first -- so on a
+ * (B,32,14,14,14) conv output it pools the (32,14,14) axes; pass C = 1 and fold the
+ * channels into B for a channels_first pool).  y is (B,A1/2,A2/2,A3/2,C); `which` (same shape,
+ * bytes, may be NULL in forward-only use) records the first maximum of every window, and the
+ * backward pass routes gy to it: gx is (B,A1,A2,A3,C), zero elsewhere. */
+int wm_maxpool3d_fwd_f32(const float *x, float *y, unsigned char *which,
+                         int B, int A1, int A2, int A3, int C, void *stream);
+int wm_maxpool3d_bwd_f32(const float *gy, const unsigned char *which, float *gx,
+                         int B, int A1, int A2, int A3, int C, void *stream);
+
 /* ------------------------------------------------------------------ least squares ------- */
 
 /* Sufficient statistics of the least-squares problem that the reference's linear Dense stacks

@@ -39,6 +39,11 @@ def lib() -> ctypes.CDLL:
         L.wm_oracle_conv2d_bwd_data.argtypes = [vp, vp, vp] + [c_int] * 7
         L.wm_oracle_conv2d_bwd_wb.argtypes = [vp, vp, vp, vp] + [c_int] * 7
         L.wm_oracle_conv2d_fwd_bwd_wb_f32.argtypes = [vp] * 7 + [c_int] * 7
+        L.wm_oracle_conv3d_fwd.argtypes = [vp, vp, vp, vp] + [c_int] * 9
+        L.wm_oracle_conv3d_bwd_data.argtypes = [vp, vp, vp] + [c_int] * 9
+        L.wm_oracle_conv3d_bwd_wb.argtypes = [vp, vp, vp, vp] + [c_int] * 9
+        L.wm_oracle_maxpool3d_fwd.argtypes = [vp, vp, vp] + [c_int] * 5
+        L.wm_oracle_maxpool3d_bwd.argtypes = [vp, vp, vp] + [c_int] * 5
         L.wm_oracle_gram.argtypes = [vp, vp, c_i64, c_int, c_int, vp]
         L.wm_oracle_gram_f32.argtypes = [vp, vp, c_i64, c_int, c_int, vp]
         L.wm_oracle_normal_solve.argtypes = [vp, c_int, c_int, c_int, c_dbl, vp]
@@ -105,6 +110,62 @@ def conv2d_fwd_bwd_wb_f32(x, w, b, gy):
     lib().wm_oracle_conv2d_fwd_bwd_wb_f32(_p(x), _p(w), _p(b), _p(gy), _p(y), _p(gw), _p(gb),
                                           N, Cin, H, W, Cout, kH, kW)
     return y, gw, gb
+
+
+def _conv3_dims(x, w):
+    B, Cin, D, H, W = x.shape
+    Cout, Cin2, kD, kH, kW = w.shape
+    if Cin != Cin2:
+        raise ValueError(f"channel mismatch: x has {Cin}, weight expects {Cin2}")
+    return B, Cin, D, H, W, Cout, kD, kH, kW
+
+
+def conv3d_fwd(x, w, b=None):
+    x, w = _f32(x), _f32(w)
+    b = None if b is None else _f32(b)
+    dims = _conv3_dims(x, w)
+    B, Cin, D, H, W, Cout, kD, kH, kW = dims
+    y = np.zeros((B, Cout, D - kD + 1, H - kH + 1, W - kW + 1), dtype=np.float64)
+    lib().wm_oracle_conv3d_fwd(_p(x), _p(w), _p(b), _p(y), *dims)
+    return y
+
+
+def conv3d_bwd_data(gy, w, x_shape):
+    gy, w = _f32(gy), _f32(w)
+    B, Cin, D, H, W = x_shape
+    Cout, _, kD, kH, kW = w.shape
+    gx = np.zeros((B, Cin, D, H, W), dtype=np.float64)
+    lib().wm_oracle_conv3d_bwd_data(_p(gy), _p(w), _p(gx), B, Cin, D, H, W, Cout, kD, kH, kW)
+    return gx
+
+
+def conv3d_bwd_wb(x, gy, w_shape):
+    x, gy = _f32(x), _f32(gy)
+    B, Cin, D, H, W = x.shape
+    Cout, _, kD, kH, kW = w_shape
+    gw = np.zeros(tuple(w_shape), dtype=np.float64)
+    gb = np.zeros((Cout,), dtype=np.float64)
+    lib().wm_oracle_conv3d_bwd_wb(_p(x), _p(gy), _p(gw), _p(gb), B, Cin, D, H, W, Cout, kD, kH, kW)
+    return gw, gb
+
+
+def maxpool3d_fwd(x):
+    """x (B,A1,A2,A3,C) -> (y, which) pooled over A1..A3 (window 2, stride 2)."""
+    x = _f32(x)
+    B, A1, A2, A3, C = x.shape
+    y = np.zeros((B, A1 // 2, A2 // 2, A3 // 2, C), dtype=np.float32)
+    which = np.zeros(y.shape, dtype=np.uint8)
+    lib().wm_oracle_maxpool3d_fwd(_p(x), _p(y), _p(which), B, A1, A2, A3, C)
+    return y, which
+
+
+def maxpool3d_bwd(gy, which, x_shape):
+    gy = _f32(gy)
+    which = np.ascontiguousarray(which, dtype=np.uint8)
+    B, A1, A2, A3, C = x_shape
+    gx = np.zeros(tuple(x_shape), dtype=np.float32)
+    lib().wm_oracle_maxpool3d_bwd(_p(gy), _p(which), _p(gx), B, A1, A2, A3, C)
+    return gx
 
 
 def gram(X, Y, acc=None, f32=False):

@@ -323,3 +323,137 @@ int wm_oracle_normal_solve(const double *acc, int F, int P, int fit_intercept, d
     free(B);
     return rc;
 }
+
+/* ------------------------------------------------------------------ 3-D operators (row a6)
+ * Conv3D / MaxPool3D of the reference's convolution.py:164-173 live in tensorflow/keras, absent
+ * here: PARITY UNPINNED against the reference's own run.  The restatement follows the published
+ * operator definition (valid cross-correlation, stride 1, channels_first) and is pinned against
+ * torch.nn.functional.conv3d / max_pool3d on CPU (tests/golden/conv3d_golden.npz), the same
+ * operator class with weights in (Cout,Cin,kD,kH,kW) order. */
+
+/* y[b,o,i,j,l] = bias[o] + sum_{c,kd,kh,kw} w[o,c,kd,kh,kw] x[b,c,i+kd,j+kh,l+kw] */
+void wm_oracle_conv3d_fwd(const float *x, const float *w, const float *b, double *y, int B,
+                          int Cin, int D, int H, int W, int Cout, int kD, int kH, int kW)
+{
+    const int OD = D - kD + 1, OH = H - kH + 1, OW = W - kW + 1;
+    if (OD <= 0 || OH <= 0 || OW <= 0) return;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int n = 0; n < B; ++n)
+        for (int o = 0; o < Cout; ++o)
+            for (int i = 0; i < OD; ++i)
+                for (int j = 0; j < OH; ++j) {
+                    double *yr = y + ((((size_t)n * Cout + o) * OD + i) * OH + j) * OW;
+                    for (int l = 0; l < OW; ++l) yr[l] = b ? (double)b[o] : 0.0;
+                    for (int c = 0; c < Cin; ++c)
+                        for (int kd = 0; kd < kD; ++kd)
+                            for (int kh = 0; kh < kH; ++kh) {
+                                const float *xr = x + ((((size_t)n * Cin + c) * D + i + kd) * H + j + kh) * W;
+                                const float *wr = w + ((((size_t)o * Cin + c) * kD + kd) * kH + kh) * kW;
+                                for (int kw = 0; kw < kW; ++kw) {
+                                    const double wv = wr[kw];
+                                    for (int l = 0; l < OW; ++l) yr[l] += wv * (double)xr[l + kw];
+                                }
+                            }
+                }
+}
+
+/* gx[b,c,p,q,r] = sum_{o,kd,kh,kw} w[o,c,kd,kh,kw] gy[b,o,p-kd,q-kh,r-kw] */
+void wm_oracle_conv3d_bwd_data(const float *gy, const float *w, double *gx, int B, int Cin, int D,
+                               int H, int W, int Cout, int kD, int kH, int kW)
+{
+    const int OD = D - kD + 1, OH = H - kH + 1, OW = W - kW + 1;
+    memset(gx, 0, sizeof(double) * (size_t)B * Cin * D * H * W);
+    if (OD <= 0 || OH <= 0 || OW <= 0) return;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int n = 0; n < B; ++n)
+        for (int c = 0; c < Cin; ++c)
+            for (int o = 0; o < Cout; ++o)
+                for (int kd = 0; kd < kD; ++kd)
+                    for (int kh = 0; kh < kH; ++kh)
+                        for (int kw = 0; kw < kW; ++kw) {
+                            const double wv = w[((((size_t)o * Cin + c) * kD + kd) * kH + kh) * kW + kw];
+                            for (int i = 0; i < OD; ++i)
+                                for (int j = 0; j < OH; ++j) {
+                                    const float *gr = gy + ((((size_t)n * Cout + o) * OD + i) * OH + j) * OW;
+                                    double *xr = gx + ((((size_t)n * Cin + c) * D + i + kd) * H + j + kh) * W + kw;
+                                    for (int l = 0; l < OW; ++l) xr[l] += wv * (double)gr[l];
+                                }
+                        }
+}
+
+/* gw[o,c,kd,kh,kw] = sum_{b,i,j,l} gy[b,o,i,j,l] x[b,c,i+kd,j+kh,l+kw];  gb[o] = sum gy[b,o,...] */
+void wm_oracle_conv3d_bwd_wb(const float *x, const float *gy, double *gw, double *gb, int B,
+                             int Cin, int D, int H, int W, int Cout, int kD, int kH, int kW)
+{
+    const int OD = D - kD + 1, OH = H - kH + 1, OW = W - kW + 1;
+    const int k3 = kD * kH * kW;
+    if (OD <= 0 || OH <= 0 || OW <= 0) return;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int o = 0; o < Cout; ++o)
+        for (int c = 0; c < Cin; ++c)
+            for (int t = 0; t < k3; ++t) {
+                const int kw = t % kW, kh = (t / kW) % kH, kd = t / (kW * kH);
+                double s = 0.0;
+                for (int n = 0; n < B; ++n)
+                    for (int i = 0; i < OD; ++i)
+                        for (int j = 0; j < OH; ++j) {
+                            const float *gr = gy + ((((size_t)n * Cout + o) * OD + i) * OH + j) * OW;
+                            const float *xr = x + ((((size_t)n * Cin + c) * D + i + kd) * H + j + kh) * W + kw;
+                            for (int l = 0; l < OW; ++l) s += (double)gr[l] * (double)xr[l];
+                        }
+                gw[((size_t)o * Cin + c) * k3 + t] = s;
+            }
+    if (gb)
+        for (int o = 0; o < Cout; ++o) {
+            double s = 0.0;
+            for (int n = 0; n < B; ++n) {
+                const float *gr = gy + ((size_t)n * Cout + o) * OD * OH * OW;
+                for (int l = 0; l < OD * OH * OW; ++l) s += (double)gr[l];
+            }
+            gb[o] = s;
+        }
+}
+
+/* 2x2x2 / stride-2 max pool over axes A1..A3 of x (B,A1,A2,A3,C); which = first maximum (0..7,
+ * A1-major).  keras.layers.MaxPool3D(pool_size=2, strides=2), padding 'valid' (floor). */
+void wm_oracle_maxpool3d_fwd(const float *x, float *y, unsigned char *which, int B, int A1, int A2,
+                             int A3, int C)
+{
+    const int P1 = A1 / 2, P2 = A2 / 2, P3 = A3 / 2;
+    for (int n = 0; n < B; ++n)
+        for (int p1 = 0; p1 < P1; ++p1)
+            for (int p2 = 0; p2 < P2; ++p2)
+                for (int p3 = 0; p3 < P3; ++p3)
+                    for (int c = 0; c < C; ++c) {
+                        float best = 0.0f;
+                        int arg = 0;
+                        for (int q = 0; q < 8; ++q) {
+                            const int a1 = 2 * p1 + (q >> 2), a2 = 2 * p2 + ((q >> 1) & 1),
+                                      a3 = 2 * p3 + (q & 1);
+                            const float v = x[((((size_t)n * A1 + a1) * A2 + a2) * A3 + a3) * C + c];
+                            if (q == 0 || v > best) { best = v; arg = q; }
+                        }
+                        const size_t o = ((((size_t)n * P1 + p1) * P2 + p2) * P3 + p3) * C + c;
+                        y[o] = best;
+                        if (which) which[o] = (unsigned char)arg;
+                    }
+}
+
+/* gradient of the pool: gy routed to the recorded maximum of each window, zero elsewhere */
+void wm_oracle_maxpool3d_bwd(const float *gy, const unsigned char *which, float *gx, int B, int A1,
+                             int A2, int A3, int C)
+{
+    const int P1 = A1 / 2, P2 = A2 / 2, P3 = A3 / 2;
+    memset(gx, 0, sizeof(float) * (size_t)B * A1 * A2 * A3 * C);
+    for (int n = 0; n < B; ++n)
+        for (int p1 = 0; p1 < P1; ++p1)
+            for (int p2 = 0; p2 < P2; ++p2)
+                for (int p3 = 0; p3 < P3; ++p3)
+                    for (int c = 0; c < C; ++c) {
+                        const size_t o = ((((size_t)n * P1 + p1) * P2 + p2) * P3 + p3) * C + c;
+                        const int q = which[o];
+                        const int a1 = 2 * p1 + (q >> 2), a2 = 2 * p2 + ((q >> 1) & 1),
+                                  a3 = 2 * p3 + (q & 1);
+                        gx[((((size_t)n * A1 + a1) * A2 + a2) * A3 + a3) * C + c] = gy[o];
+                    }
+}

@@ -46,3 +46,23 @@ def grid721_inputs(N=2):
     b = synth.uniform(5, (1,), -1.0 / 3, 1.0 / 3)
     gy = synth.uniform(4, (N, 1, H - 2, W - 2), -1.0, 1.0)
     return x, w, b, gy
+
+# name, B, Cin, (D,H,W), Cout, (kD,kH,kW), seed, stride of the stored subsample
+CONV3D_CASES = [
+    ("small", 2, 3, (6, 7, 8), 5, (3, 2, 4), 31, 1),
+    ("edge_one_output", 1, 2, (3, 4, 5), 17, (3, 4, 5), 32, 1),
+    ("ragged_channels", 3, 33, (5, 5, 6), 18, (2, 3, 2), 33, 1),
+    ("ref_layer1", 2, 1, (20, 20, 20), 32, (7, 7, 7), 34, 5),
+    ("ref_layer2", 2, 16, (7, 7, 14), 64, (5, 5, 5), 35, 3),
+]
+
+
+def conv3d_inputs(case):
+    name, B, Cin, dhw, Cout, k, seed, _ = case
+    x = synth.uniform(seed * 10 + 1, (B, Cin) + dhw)
+    bound = 1.0 / np.sqrt(Cin * k[0] * k[1] * k[2])
+    w = synth.uniform(seed * 10 + 2, (Cout, Cin) + k, -bound, bound)
+    b = synth.uniform(seed * 10 + 3, (Cout,), -bound, bound)
+    out = tuple(d - kk + 1 for d, kk in zip(dhw, k))
+    gy = synth.uniform(seed * 10 + 4, (B, Cout) + out, -1.0, 1.0)
+    return x, w, b, gy

@@ -226,6 +226,61 @@ def regression_goldens():
     np.savez_compressed(os.path.join(HERE, "regression_golden.npz"), **fix)
 
 
+CONV3D_CASES = [
+    # name, B, Cin, (D,H,W), Cout, (kD,kH,kW), seed, stride of the stored subsample
+    ("small", 2, 3, (6, 7, 8), 5, (3, 2, 4), 31, 1),
+    ("edge_one_output", 1, 2, (3, 4, 5), 17, (3, 4, 5), 32, 1),        # D=kD..: one output each
+    ("ragged_channels", 3, 33, (5, 5, 6), 18, (2, 3, 2), 33, 1),       # not multiples of 16
+    ("ref_layer1", 2, 1, (20, 20, 20), 32, (7, 7, 7), 34, 5),          # convolution.py:164
+    ("ref_layer2", 2, 16, (7, 7, 14), 64, (5, 5, 5), 35, 3),           # convolution.py:166 (2b)
+]
+
+
+def conv3d_inputs(case):
+    name, B, Cin, dhw, Cout, k, seed, _ = case
+    x = synth.uniform(seed * 10 + 1, (B, Cin) + dhw)
+    bound = 1.0 / np.sqrt(Cin * k[0] * k[1] * k[2])
+    w = synth.uniform(seed * 10 + 2, (Cout, Cin) + k, -bound, bound)
+    b = synth.uniform(seed * 10 + 3, (Cout,), -bound, bound)
+    out = tuple(d - kk + 1 for d, kk in zip(dhw, k))
+    gy = synth.uniform(seed * 10 + 4, (B, Cout) + out, -1.0, 1.0)
+    return x, w, b, gy
+
+
+def conv3d_goldens():
+    """torch.nn.functional.conv3d (+ autograd) and max_pool3d on CPU in float64: the library
+    operator class of keras Conv3D/MaxPool3D (valid, stride 1, channels_first).  NOT the
+    reference's own run (tensorflow absent) -- pins the operator definition only."""
+    import torch.nn.functional as F
+    fix = {}
+    for case in CONV3D_CASES:
+        name, stride = case[0], case[7]
+        x, w, b, gy = conv3d_inputs(case)
+        xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+        wt = torch.tensor(w, dtype=torch.float64, requires_grad=True)
+        bt = torch.tensor(b, dtype=torch.float64, requires_grad=True)
+        y = F.conv3d(xt, wt, bt)
+        y.backward(torch.tensor(gy, dtype=torch.float64))
+        for key, val in (("y", y.detach()), ("gx", xt.grad), ("gw", wt.grad), ("gb", bt.grad)):
+            flat = val.numpy().ravel()
+            fix[f"{name}/{key}"] = flat[::stride].copy()
+            fix[f"{name}/{key}_sum"] = np.array(flat.sum())
+            fix[f"{name}/{key}_absmax"] = np.array(np.abs(flat).max())
+    # pool: channels_last window over axes 1..3, as the reference's MaxPool3D runs (2b)
+    xp = synth.uniform(361, (2, 32, 14, 14, 14), -1.0, 1.0)
+    yp = F.max_pool3d(torch.tensor(xp, dtype=torch.float64, requires_grad=True).permute(0, 4, 1, 2, 3),
+                      2, 2).permute(0, 2, 3, 4, 1).contiguous()
+    fix["pool/y"] = yp.detach().numpy().astype(np.float32)
+    xo = synth.uniform(362, (1, 5, 7, 4, 3), -1.0, 1.0)                 # odd sides: floor
+    xot = torch.tensor(xo, dtype=torch.float64, requires_grad=True)
+    yo = F.max_pool3d(xot.permute(0, 4, 1, 2, 3), 2, 2).permute(0, 2, 3, 4, 1).contiguous()
+    gyo = synth.uniform(363, tuple(yo.shape), -1.0, 1.0)
+    yo.backward(torch.tensor(gyo, dtype=torch.float64))
+    fix["pool_odd/y"] = yo.detach().numpy().astype(np.float32)
+    fix["pool_odd/gx"] = xot.grad.numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, "conv3d_golden.npz"), **fix)
+
+
 def data_goldens():
     """Outputs of the reference's data.py (imported with stubs for xarray and netCDF4, which it
     only needs for file I/O) on a fake 5-file data set built by tests/fakes.py -- pins the pooled
@@ -261,10 +316,14 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "data":
         data_goldens()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "conv3d":
+        conv3d_goldens()
+        sys.exit(0)
     model_goldens()
     conv_goldens()
     regression_goldens()
     data_goldens()
+    conv3d_goldens()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -19,6 +19,12 @@ SIGNATURES = {
     "wm_conv2d_bwd_data_f32": (c_int, [vp, vp, vp] + [c_int] * 7 + [vp]),
     "wm_conv2d_bwd_wb_workspace_bytes": (c_sz, [c_int] * 7),
     "wm_conv2d_bwd_wb_f32": (c_int, [vp, vp, vp, vp, vp, c_sz] + [c_int] * 7 + [vp]),
+    "wm_conv3d_fwd_f32": (c_int, [vp, vp, vp, vp] + [c_int] * 9 + [c_int, vp]),
+    "wm_conv3d_bwd_data_f32": (c_int, [vp, vp, vp] + [c_int] * 9 + [vp]),
+    "wm_conv3d_bwd_wb_workspace_bytes": (c_sz, [c_int] * 9),
+    "wm_conv3d_bwd_wb_f32": (c_int, [vp, vp, vp, vp, vp, c_sz] + [c_int] * 9 + [vp]),
+    "wm_maxpool3d_fwd_f32": (c_int, [vp, vp, vp] + [c_int] * 5 + [vp]),
+    "wm_maxpool3d_bwd_f32": (c_int, [vp, vp, vp] + [c_int] * 5 + [vp]),
     "wm_gram_workspace_bytes": (c_sz, [c_i64, c_int, c_int]),
     "wm_gram_f32": (c_int, [vp, vp, c_i64, c_int, c_int, vp, vp, c_sz, vp]),
     "wm_normal_solve_workspace_bytes": (c_sz, [c_int, c_int]),

@@ -1,0 +1,443 @@
+// conv3d.hip -- 3-D cross-correlation (valid, stride 1, channels_first) forward / backward and the
+// 2x2x2 max pool of the reference's Conv3D model:
+//   keras.layers.Conv3D(32, 7, strides=1, data_format="channels_first")   convolution.py:164,170
+//   keras.layers.Conv3D(64, 5, strides=1, data_format="channels_first")   convolution.py:166,172
+//   keras.layers.MaxPool3D(pool_size=2, strides=2)                        convolution.py:165,167
+//
+// All three conv passes are implicit GEMMs on v_mfma_f32_16x16x4_f32 (exact fp32 products and
+// fp32 accumulation, MI355X_MICROARCH.md), one 16x16 output tile per wave, operands gathered
+// straight from global memory / L2 (the tensors of this model are a few MB):
+//   forward   Y[o, n]  = sum_k  W[o, k]   Xcol[k, n]     k = (c,kd,kh,kw), n = (b,od,oh,ow)
+//   bwd data  GX[c, m] = sum_kk W[kk, c]  GYcol[kk, m]   kk = (o,kd,kh,kw), m = (b,d,h,w)
+//   bwd w,b   GW[o, k] = sum_n  GY[o, n]  Xcol[k, n]     (+ a column of ones for the bias)
+// The k -> tensor-offset decode is done once per workgroup into an LDS table (chunks of 4096
+// entries); the weight/bias gradient is split over n-chunks of 1024 outputs, written as float64
+// partials and combined in a fixed order (bitwise reproducible, no atomics).
+#include "common.h"
+
+namespace {
+
+constexpr int BLOCK = 256;
+constexpr int WAVES = BLOCK / 64;
+constexpr int KCHUNK = 4096;      // table entries resident in LDS at a time
+constexpr int NCHUNK = 1024;      // outputs per weight-gradient split
+
+struct Dims3 {
+    int B, Cin, D, H, W, Cout, kD, kH, kW, OD, OH, OW;
+};
+
+__device__ __forceinline__ f32x4 mma(float a, float b, f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// offset of tap k = (c,kd,kh,kw) relative to the window origin inside one batch item of x
+__device__ __forceinline__ int tap_offset(const Dims3 &d, int k)
+{
+    const int kw = k % d.kW;
+    int t = k / d.kW;
+    const int kh = t % d.kH;
+    t /= d.kH;
+    const int kd = t % d.kD;
+    const int c = t / d.kD;
+    return ((c * d.D + kd) * d.H + kh) * d.W + kw;
+}
+
+// ------------------------------------------------------------------------------ forward
+template <int OT>   // OT 16-row tiles of output channels per wave
+__global__ __launch_bounds__(BLOCK) void conv3d_fwd_kernel(const float *__restrict__ x,
+                                                           const float *__restrict__ w,
+                                                           const float *__restrict__ bias,
+                                                           float *__restrict__ y, Dims3 d, int K,
+                                                           int Ntot, int relu)
+{
+    __shared__ int off[KCHUNK];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
+    const int S = d.OD * d.OH * d.OW;
+    const int tile = blockIdx.x * WAVES + wave;
+    int n = tile * 16 + j;
+    const bool nvalid = n < Ntot;
+    if (!nvalid) n = Ntot - 1;                       // keep the gathers in bounds; never stored
+    const int b_ = n / S, sp = n % S;
+    const int ow = sp % d.OW, oh = (sp / d.OW) % d.OH, od = sp / (d.OW * d.OH);
+    const size_t nbase = (((size_t)b_ * d.Cin * d.D + od) * d.H + oh) * d.W + ow;
+
+    f32x4 acc[OT];
+#pragma unroll
+    for (int t = 0; t < OT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int kc = 0; kc < K; kc += KCHUNK) {
+        const int kn = min(KCHUNK, K - kc);
+        const int kn4 = (kn + 3) & ~3;
+        __syncthreads();
+        for (int k = tid; k < kn4; k += BLOCK) off[k] = k < kn ? tap_offset(d, kc + k) : 0;
+        __syncthreads();
+        for (int k0 = 0; k0 < kn4; k0 += 4) {
+            const int k = k0 + g;
+            const float xv = x[nbase + off[k]];
+#pragma unroll
+            for (int t = 0; t < OT; ++t) {
+                const int o = t * 16 + j;
+                const float wv = (k < kn && o < d.Cout) ? w[(size_t)o * K + kc + k] : 0.0f;
+                acc[t] = mma(wv, xv, acc[t]);
+            }
+        }
+    }
+    if (!nvalid) return;
+#pragma unroll
+    for (int t = 0; t < OT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int o = t * 16 + 4 * g + r;
+            if (o < d.Cout) {
+                float v = acc[t][r] + (bias ? bias[o] : 0.0f);
+                if (relu) v = fmaxf(v, 0.0f);
+                y[((size_t)b_ * d.Cout + o) * S + sp] = v;
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------ backward data
+// table entry for kk = (o,kd,kh,kw): o << 24 | kd << 16 | kh << 8 | kw
+template <int CT>   // CT 16-row tiles of input channels per wave
+__global__ __launch_bounds__(BLOCK) void conv3d_bwd_data_kernel(const float *__restrict__ gy,
+                                                                const float *__restrict__ w,
+                                                                float *__restrict__ gx, Dims3 d,
+                                                                int K2, int Mtot)
+{
+    __shared__ int tab[KCHUNK];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
+    const int k3 = d.kD * d.kH * d.kW;
+    const int S = d.OD * d.OH * d.OW, V = d.D * d.H * d.W;
+    const int tile = blockIdx.x * WAVES + wave;
+    int m = tile * 16 + j;
+    const bool mvalid = m < Mtot;
+    if (!mvalid) m = Mtot - 1;
+    const int b_ = m / V, pos = m % V;
+    const int pw = pos % d.W, ph = (pos / d.W) % d.H, pd = pos / (d.W * d.H);
+    const size_t gybase = (size_t)b_ * d.Cout * S;
+
+    f32x4 acc[CT];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int kc = 0; kc < K2; kc += KCHUNK) {
+        const int kn = min(KCHUNK, K2 - kc);
+        const int kn4 = (kn + 3) & ~3;
+        __syncthreads();
+        for (int k = tid; k < kn4; k += BLOCK) {
+            int e = -1;                               // padding: never in range
+            if (k < kn) {
+                const int kk = kc + k;
+                const int o = kk / k3, r = kk % k3;
+                const int kw = r % d.kW, kh = (r / d.kW) % d.kH, kd = r / (d.kW * d.kH);
+                e = (o << 24) | (kd << 16) | (kh << 8) | kw;
+            }
+            tab[k] = e;
+        }
+        __syncthreads();
+        for (int k0 = 0; k0 < kn4; k0 += 4) {
+            const int e = tab[k0 + g];
+            const int o = (e >> 24) & 0xff, kd = (e >> 16) & 0xff, kh = (e >> 8) & 0xff,
+                      kw = e & 0xff;
+            const int od = pd - kd, oh = ph - kh, ow = pw - kw;
+            const bool in = e >= 0 && od >= 0 && od < d.OD && oh >= 0 && oh < d.OH && ow >= 0 &&
+                            ow < d.OW;
+            const float gv = in ? gy[gybase + (size_t)o * S + (od * d.OH + oh) * d.OW + ow] : 0.0f;
+            const int wsp = (kd * d.kH + kh) * d.kW + kw;
+#pragma unroll
+            for (int t = 0; t < CT; ++t) {
+                const int c = t * 16 + j;
+                const float wv = (e >= 0 && c < d.Cin) ? w[((size_t)o * d.Cin + c) * k3 + wsp] : 0.0f;
+                acc[t] = mma(wv, gv, acc[t]);
+            }
+        }
+    }
+    if (!mvalid) return;
+#pragma unroll
+    for (int t = 0; t < CT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = t * 16 + 4 * g + r;
+            if (c < d.Cin) gx[((size_t)b_ * d.Cin + c) * V + pos] = acc[t][r];
+        }
+}
+
+// ------------------------------------------------------------------------------ backward w, b
+// grid = (ceil(tiles / WAVES), splits); tile = (o-tile, k-tile) with k in [0, K] (k == K is the
+// bias column of ones).  partial is [splits][nent] float64, nent = Cout*K + Cout.
+__global__ __launch_bounds__(BLOCK) void conv3d_bwd_wb_kernel(const float *__restrict__ x,
+                                                              const float *__restrict__ gy,
+                                                              double *__restrict__ partial,
+                                                              Dims3 d, int K, int Ntot, int ktiles,
+                                                              int tiles)
+{
+    __shared__ int xbase[NCHUNK];     // window origin in x of output n
+    __shared__ int gbase[NCHUNK];     // index of gy[b, 0, sp]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
+    const int S = d.OD * d.OH * d.OW;
+    const int n0 = blockIdx.y * NCHUNK;
+    const int nn = min(NCHUNK, Ntot - n0);
+    const int nn4 = (nn + 3) & ~3;
+    for (int t = tid; t < nn4; t += BLOCK) {
+        int xb = 0, gb = 0;
+        if (t < nn) {
+            const int n = n0 + t;
+            const int b_ = n / S, sp = n % S;
+            const int ow = sp % d.OW, oh = (sp / d.OW) % d.OH, od = sp / (d.OW * d.OH);
+            xb = ((b_ * d.Cin * d.D + od) * d.H + oh) * d.W + ow;
+            gb = b_ * d.Cout * S + sp;
+        }
+        xbase[t] = xb;
+        gbase[t] = gb;
+    }
+    __syncthreads();
+    const int tile = blockIdx.x * WAVES + wave;
+    if (tile >= tiles) return;
+    const int ot = tile / ktiles, kt = tile % ktiles;
+    const int o_a = ot * 16 + j;                       // A operand row (output channel)
+    const int k_b = kt * 16 + j;                       // B operand column (tap)
+    const int koff = k_b < K ? tap_offset(d, k_b) : 0;
+    const bool a_ok = o_a < d.Cout;
+    const size_t a_off = (size_t)o_a * S;
+
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int t0 = 0; t0 < nn4; t0 += 4) {
+        const int t = t0 + g;
+        const bool tv = t < nn;
+        const float gv = (tv && a_ok) ? gy[gbase[t] + a_off] : 0.0f;
+        float xv = 0.0f;
+        if (tv) xv = k_b < K ? x[xbase[t] + koff] : (k_b == K ? 1.0f : 0.0f);
+        acc = mma(gv, xv, acc);
+    }
+    const int nw = d.Cout * K, nent = nw + d.Cout;
+    double *dst = partial + (size_t)blockIdx.y * nent;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int o = ot * 16 + 4 * g + r;
+        if (o < d.Cout) {
+            if (k_b < K) dst[(size_t)o * K + k_b] = (double)acc[r];
+            else if (k_b == K) dst[nw + o] = (double)acc[r];
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void conv3d_reduce_kernel(const double *__restrict__ partial,
+                                                           int nparts, int nent, int nw,
+                                                           float *__restrict__ gw,
+                                                           float *__restrict__ gb)
+{
+    const int e = blockIdx.x * 64 + threadIdx.x;
+    if (e >= nent) return;
+    double s = 0.0;
+    for (int p = 0; p < nparts; ++p) s += partial[(size_t)p * nent + e];
+    if (e < nw) gw[e] = (float)s;
+    else if (gb) gb[e - nw] = (float)s;
+}
+
+// ------------------------------------------------------------------------------ max pool
+// x is (B, A1, A2, A3, C) contiguous; window 2, stride 2 over A1..A3 -> (B, A1/2, A2/2, A3/2, C).
+// which[out] = position (0..7, a1-major) of the first maximum of the window.
+__global__ __launch_bounds__(BLOCK) void maxpool3d_fwd_kernel(const float *__restrict__ x,
+                                                              float *__restrict__ y,
+                                                              unsigned char *__restrict__ which,
+                                                              int B, int A1, int A2, int A3, int C,
+                                                              long long total)
+{
+    const int P1 = A1 / 2, P2 = A2 / 2, P3 = A3 / 2;
+    for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < total;
+         i += (long long)gridDim.x * BLOCK) {
+        const int c = (int)(i % C);
+        long long t = i / C;
+        const int p3 = (int)(t % P3); t /= P3;
+        const int p2 = (int)(t % P2); t /= P2;
+        const int p1 = (int)(t % P1);
+        const long long b_ = t / P1;
+        float best = 0.0f;
+        int arg = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int a1 = 2 * p1 + (q >> 2), a2 = 2 * p2 + ((q >> 1) & 1), a3 = 2 * p3 + (q & 1);
+            const float v = x[(((b_ * A1 + a1) * A2 + a2) * A3 + a3) * C + c];
+            if (q == 0 || v > best) { best = v; arg = q; }
+        }
+        y[i] = best;
+        if (which) which[i] = (unsigned char)arg;
+    }
+}
+
+// one thread per INPUT element: windows do not overlap, so no atomics are needed
+__global__ __launch_bounds__(BLOCK) void maxpool3d_bwd_kernel(const float *__restrict__ gy,
+                                                              const unsigned char *__restrict__ which,
+                                                              float *__restrict__ gx, int B, int A1,
+                                                              int A2, int A3, int C, long long total)
+{
+    const int P1 = A1 / 2, P2 = A2 / 2, P3 = A3 / 2;
+    for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < total;
+         i += (long long)gridDim.x * BLOCK) {
+        const int c = (int)(i % C);
+        long long t = i / C;
+        const int a3 = (int)(t % A3); t /= A3;
+        const int a2 = (int)(t % A2); t /= A2;
+        const int a1 = (int)(t % A1);
+        const long long b_ = t / A1;
+        const int p1 = a1 >> 1, p2 = a2 >> 1, p3 = a3 >> 1;
+        float v = 0.0f;
+        if (p1 < P1 && p2 < P2 && p3 < P3) {
+            const long long o = (((b_ * P1 + p1) * P2 + p2) * P3 + p3) * C + c;
+            const int q = ((a1 & 1) << 2) | ((a2 & 1) << 1) | (a3 & 1);
+            if (which[o] == q) v = gy[o];
+        }
+        gx[i] = v;
+    }
+}
+
+int fill_dims(Dims3 *d, int B, int Cin, int D, int H, int W, int Cout, int kD, int kH, int kW)
+{
+    WM_REQUIRE(B > 0 && Cin > 0 && D > 0 && H > 0 && W > 0 && Cout > 0 && kD > 0 && kH > 0 && kW > 0,
+               WM_ERR_INVALID, "conv3d: non-positive dimension");
+    WM_REQUIRE(kD <= D && kH <= H && kW <= W, WM_ERR_INVALID,
+               "conv3d: kernel (%d,%d,%d) larger than input (%d,%d,%d)", kD, kH, kW, D, H, W);
+    WM_REQUIRE(kD < 256 && kH < 256 && kW < 256 && Cout <= 64 && Cin <= 64, WM_ERR_UNSUPPORTED,
+               "conv3d: kernel sides < 256 and at most 64 channels per side are implemented "
+               "(Cin=%d Cout=%d)", Cin, Cout);
+    d->B = B; d->Cin = Cin; d->D = D; d->H = H; d->W = W; d->Cout = Cout;
+    d->kD = kD; d->kH = kH; d->kW = kW;
+    d->OD = D - kD + 1; d->OH = H - kH + 1; d->OW = W - kW + 1;
+    // 32-bit index arithmetic inside the kernels
+    const long long xin = (long long)B * Cin * D * H * W;
+    const long long yout = (long long)B * Cout * d->OD * d->OH * d->OW;
+    const long long wn = (long long)Cout * Cin * kD * kH * kW;
+    WM_REQUIRE(xin < (1ll << 31) && yout < (1ll << 31) && wn < (1ll << 31), WM_ERR_UNSUPPORTED,
+               "conv3d: tensors of 2^31 elements or more are not implemented");
+    return WM_OK;
+}
+
+}  // namespace
+
+extern "C" int wm_conv3d_fwd_f32(const float *x, const float *w, const float *b, float *y, int B,
+                                 int Cin, int D, int H, int W, int Cout, int kD, int kH, int kW,
+                                 int relu, void *stream)
+{
+    WM_REQUIRE(x && w && y, WM_ERR_INVALID, "wm_conv3d_fwd_f32: null pointer");
+    Dims3 d;
+    if (int rc = fill_dims(&d, B, Cin, D, H, W, Cout, kD, kH, kW)) return rc;
+    WM_REQUIRE(wm_num_cus() > 0, WM_ERR_NO_DEVICE, "wm_conv3d_fwd_f32: no HIP device");
+    const int K = Cin * kD * kH * kW;
+    const int Ntot = B * d.OD * d.OH * d.OW;
+    const int blocks = ((Ntot + 15) / 16 + WAVES - 1) / WAVES;
+    hipStream_t st = (hipStream_t)stream;
+    const int ot = (Cout + 15) / 16;
+    if (ot == 1)
+        hipLaunchKernelGGL(conv3d_fwd_kernel<1>, dim3(blocks), dim3(BLOCK), 0, st, x, w, b, y, d, K,
+                           Ntot, relu);
+    else if (ot == 2)
+        hipLaunchKernelGGL(conv3d_fwd_kernel<2>, dim3(blocks), dim3(BLOCK), 0, st, x, w, b, y, d, K,
+                           Ntot, relu);
+    else
+        hipLaunchKernelGGL(conv3d_fwd_kernel<4>, dim3(blocks), dim3(BLOCK), 0, st, x, w, b, y, d, K,
+                           Ntot, relu);
+    WM_LAUNCH_CHECK("conv3d_fwd_kernel");
+    return WM_OK;
+}
+
+extern "C" int wm_conv3d_bwd_data_f32(const float *gy, const float *w, float *gx, int B, int Cin,
+                                      int D, int H, int W, int Cout, int kD, int kH, int kW,
+                                      void *stream)
+{
+    WM_REQUIRE(gy && w && gx, WM_ERR_INVALID, "wm_conv3d_bwd_data_f32: null pointer");
+    Dims3 d;
+    if (int rc = fill_dims(&d, B, Cin, D, H, W, Cout, kD, kH, kW)) return rc;
+    WM_REQUIRE(wm_num_cus() > 0, WM_ERR_NO_DEVICE, "wm_conv3d_bwd_data_f32: no HIP device");
+    const int K2 = Cout * kD * kH * kW;
+    const int Mtot = B * D * H * W;
+    const int blocks = ((Mtot + 15) / 16 + WAVES - 1) / WAVES;
+    hipStream_t st = (hipStream_t)stream;
+    const int ct = (Cin + 15) / 16;
+    if (ct == 1)
+        hipLaunchKernelGGL(conv3d_bwd_data_kernel<1>, dim3(blocks), dim3(BLOCK), 0, st, gy, w, gx, d,
+                           K2, Mtot);
+    else if (ct == 2)
+        hipLaunchKernelGGL(conv3d_bwd_data_kernel<2>, dim3(blocks), dim3(BLOCK), 0, st, gy, w, gx, d,
+                           K2, Mtot);
+    else
+        hipLaunchKernelGGL(conv3d_bwd_data_kernel<4>, dim3(blocks), dim3(BLOCK), 0, st, gy, w, gx, d,
+                           K2, Mtot);
+    WM_LAUNCH_CHECK("conv3d_bwd_data_kernel");
+    return WM_OK;
+}
+
+extern "C" size_t wm_conv3d_bwd_wb_workspace_bytes(int B, int Cin, int D, int H, int W, int Cout,
+                                                   int kD, int kH, int kW)
+{
+    if (B <= 0 || Cin <= 0 || D <= 0 || H <= 0 || W <= 0 || Cout <= 0 || kD <= 0 || kH <= 0 ||
+        kW <= 0 || kD > D || kH > H || kW > W)
+        return 0;
+    const long long Ntot = (long long)B * (D - kD + 1) * (H - kH + 1) * (W - kW + 1);
+    const size_t splits = (size_t)((Ntot + NCHUNK - 1) / NCHUNK);
+    const size_t nent = (size_t)Cout * Cin * kD * kH * kW + Cout;
+    return wm_align_up(splits * nent * sizeof(double), 256);
+}
+
+extern "C" int wm_conv3d_bwd_wb_f32(const float *x, const float *gy, float *gw, float *gb,
+                                    void *workspace, size_t workspace_bytes, int B, int Cin, int D,
+                                    int H, int W, int Cout, int kD, int kH, int kW, void *stream)
+{
+    WM_REQUIRE(x && gy && gw, WM_ERR_INVALID, "wm_conv3d_bwd_wb_f32: null pointer");
+    Dims3 d;
+    if (int rc = fill_dims(&d, B, Cin, D, H, W, Cout, kD, kH, kW)) return rc;
+    WM_REQUIRE(wm_num_cus() > 0, WM_ERR_NO_DEVICE, "wm_conv3d_bwd_wb_f32: no HIP device");
+    const size_t need = wm_conv3d_bwd_wb_workspace_bytes(B, Cin, D, H, W, Cout, kD, kH, kW);
+    WM_REQUIRE(workspace && workspace_bytes >= need, WM_ERR_WORKSPACE,
+               "wm_conv3d_bwd_wb_f32: workspace of %zu bytes needed, %zu given", need,
+               workspace_bytes);
+    const int K = Cin * kD * kH * kW;
+    const int Ntot = B * d.OD * d.OH * d.OW;
+    const int splits = (Ntot + NCHUNK - 1) / NCHUNK;
+    WM_REQUIRE(splits <= 65535, WM_ERR_UNSUPPORTED, "wm_conv3d_bwd_wb_f32: too many outputs");
+    const int ktiles = (K + 1 + 15) / 16, otiles = (Cout + 15) / 16;
+    const int tiles = ktiles * otiles;
+    const int nw = Cout * K, nent = nw + Cout;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(conv3d_bwd_wb_kernel, dim3((tiles + WAVES - 1) / WAVES, splits), dim3(BLOCK),
+                       0, st, x, gy, (double *)workspace, d, K, Ntot, ktiles, tiles);
+    WM_LAUNCH_CHECK("conv3d_bwd_wb_kernel");
+    hipLaunchKernelGGL(conv3d_reduce_kernel, dim3((nent + 63) / 64), dim3(64), 0, st,
+                       (const double *)workspace, splits, nent, nw, gw, gb);
+    WM_LAUNCH_CHECK("conv3d_reduce_kernel");
+    return WM_OK;
+}
+
+extern "C" int wm_maxpool3d_fwd_f32(const float *x, float *y, unsigned char *which, int B, int A1,
+                                    int A2, int A3, int C, void *stream)
+{
+    WM_REQUIRE(x && y, WM_ERR_INVALID, "wm_maxpool3d_fwd_f32: null pointer");
+    WM_REQUIRE(B > 0 && A1 >= 2 && A2 >= 2 && A3 >= 2 && C > 0, WM_ERR_INVALID,
+               "wm_maxpool3d_fwd_f32: pooled axes need at least 2 entries (%d,%d,%d)", A1, A2, A3);
+    const int cus = wm_num_cus();
+    WM_REQUIRE(cus > 0, WM_ERR_NO_DEVICE, "wm_maxpool3d_fwd_f32: no HIP device");
+    const long long total = (long long)B * (A1 / 2) * (A2 / 2) * (A3 / 2) * C;
+    long long blocks = (total + BLOCK - 1) / BLOCK;
+    if (blocks > (long long)cus * 16) blocks = (long long)cus * 16;
+    hipLaunchKernelGGL(maxpool3d_fwd_kernel, dim3((int)blocks), dim3(BLOCK), 0, (hipStream_t)stream,
+                       x, y, which, B, A1, A2, A3, C, total);
+    WM_LAUNCH_CHECK("maxpool3d_fwd_kernel");
+    return WM_OK;
+}
+
+extern "C" int wm_maxpool3d_bwd_f32(const float *gy, const unsigned char *which, float *gx, int B,
+                                    int A1, int A2, int A3, int C, void *stream)
+{
+    WM_REQUIRE(gy && which && gx, WM_ERR_INVALID, "wm_maxpool3d_bwd_f32: null pointer");
+    WM_REQUIRE(B > 0 && A1 >= 2 && A2 >= 2 && A3 >= 2 && C > 0, WM_ERR_INVALID,
+               "wm_maxpool3d_bwd_f32: pooled axes need at least 2 entries (%d,%d,%d)", A1, A2, A3);
+    const int cus = wm_num_cus();
+    WM_REQUIRE(cus > 0, WM_ERR_NO_DEVICE, "wm_maxpool3d_bwd_f32: no HIP device");
+    const long long total = (long long)B * A1 * A2 * A3 * C;
+    long long blocks = (total + BLOCK - 1) / BLOCK;
+    if (blocks > (long long)cus * 16) blocks = (long long)cus * 16;
+    hipLaunchKernelGGL(maxpool3d_bwd_kernel, dim3((int)blocks), dim3(BLOCK), 0, (hipStream_t)stream,
+                       gy, which, gx, B, A1, A2, A3, C, total);
+    WM_LAUNCH_CHECK("maxpool3d_bwd_kernel");
+    return WM_OK;
+}

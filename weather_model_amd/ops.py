@@ -119,6 +119,147 @@ def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
     return y.squeeze(0) if unbatched else y
 
 
+# --------------------------------------------------------------------------- conv3d / pool
+
+def _conv3_dims(x, w):
+    if x.dim() != 5 or w.dim() != 5:
+        raise ValueError(f"conv3d expects (B,Cin,D,H,W) input and (Cout,Cin,kD,kH,kW) weight, got "
+                         f"{tuple(x.shape)} and {tuple(w.shape)}")
+    B, Cin, D, H, W = x.shape
+    Cout, Cin2, kD, kH, kW = w.shape
+    if Cin != Cin2:
+        raise RuntimeError(f"conv3d: expected input with {Cin2} channels, got {Cin}")
+    if kD > D or kH > H or kW > W:
+        raise RuntimeError(f"conv3d: kernel size ({kD},{kH},{kW}) can't be greater than input "
+                           f"({D},{H},{W})")
+    return B, Cin, D, H, W, Cout, kD, kH, kW
+
+
+def conv3d_forward(x, w, b=None, relu=False):
+    x, w = _req(x, "input"), _req(w, "weight")
+    b = None if b is None else _req(b, "bias")
+    dims = _conv3_dims(x, w)
+    B, Cin, D, H, W, Cout, kD, kH, kW = dims
+    y = torch.empty((B, Cout, D - kD + 1, H - kH + 1, W - kW + 1), device=x.device,
+                    dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().wm_conv3d_fwd_f32(
+            x.data_ptr(), w.data_ptr(), 0 if b is None else b.data_ptr(), y.data_ptr(), *dims,
+            int(bool(relu)), _stream()))
+    return y
+
+
+def conv3d_backward_data(gy, w, x_shape):
+    gy, w = _req(gy, "grad_output"), _req(w, "weight")
+    B, Cin, D, H, W = x_shape
+    Cout, _, kD, kH, kW = w.shape
+    gx = torch.empty((B, Cin, D, H, W), device=gy.device, dtype=torch.float32)
+    with torch.cuda.device(gy.device):
+        _lib.check(_lib.lib().wm_conv3d_bwd_data_f32(
+            gy.data_ptr(), w.data_ptr(), gx.data_ptr(), B, Cin, D, H, W, Cout, kD, kH, kW,
+            _stream()))
+    return gx
+
+
+def conv3d_backward_wb(x, gy, w_shape, need_bias=True):
+    x, gy = _req(x, "input"), _req(gy, "grad_output")
+    B, Cin, D, H, W = x.shape
+    Cout, _, kD, kH, kW = w_shape
+    dims = (B, Cin, D, H, W, Cout, kD, kH, kW)
+    L = _lib.lib()
+    with torch.cuda.device(x.device):
+        nbytes = L.wm_conv3d_bwd_wb_workspace_bytes(*dims)
+        ws = torch.empty((max(nbytes, 8),), device=x.device, dtype=torch.uint8)
+        gw = torch.empty(tuple(w_shape), device=x.device, dtype=torch.float32)
+        gb = torch.empty((Cout,), device=x.device, dtype=torch.float32) if need_bias else None
+        _lib.check(L.wm_conv3d_bwd_wb_f32(
+            x.data_ptr(), gy.data_ptr(), gw.data_ptr(), 0 if gb is None else gb.data_ptr(),
+            ws.data_ptr(), ws.numel(), *dims, _stream()))
+    return gw, gb
+
+
+class Conv3dFunction(torch.autograd.Function):
+    """autograd node for the Conv3D layers of convolution.py:164-172."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return conv3d_forward(x, w, b)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = conv3d_backward_data(gy, w, x.shape) if ctx.needs_input_grad[0] else None
+        gw = gb = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            gw, gb = conv3d_backward_wb(x, gy, w.shape, need_bias=ctx.has_bias)
+        return gx, gw, gb
+
+
+def conv3d(input, weight, bias=None):
+    """3-D cross-correlation, valid padding, stride 1, channels_first."""
+    return Conv3dFunction.apply(input, weight, bias)
+
+
+def maxpool3d_forward(x, channels_last=True, want_index=True):
+    """2x2x2 / stride-2 max pool of a 5-D tensor over axes (1,2,3) (``channels_last``, the Keras
+    default the reference runs with) or (2,3,4).  Returns (y, which)."""
+    x = _req(x, "input")
+    if x.dim() != 5:
+        raise ValueError(f"maxpool3d expects a 5-D tensor, got {tuple(x.shape)}")
+    if channels_last:
+        B, A1, A2, A3, C = x.shape
+        out_shape = (B, A1 // 2, A2 // 2, A3 // 2, C)
+    else:
+        b0, c0, A1, A2, A3 = x.shape
+        B, C = b0 * c0, 1
+        out_shape = (b0, c0, A1 // 2, A2 // 2, A3 // 2)
+    if min(A1, A2, A3) < 2:
+        raise RuntimeError(f"maxpool3d: pooled axes ({A1},{A2},{A3}) are smaller than the window")
+    y = torch.empty(out_shape, device=x.device, dtype=torch.float32)
+    which = torch.empty(out_shape, device=x.device, dtype=torch.uint8) if want_index else None
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().wm_maxpool3d_fwd_f32(
+            x.data_ptr(), y.data_ptr(), 0 if which is None else which.data_ptr(), B, A1, A2, A3, C,
+            _stream()))
+    return y, which
+
+
+def maxpool3d_backward(gy, which, x_shape, channels_last=True):
+    gy = _req(gy, "grad_output")
+    which = _req(which, "which", torch.uint8)
+    if channels_last:
+        B, A1, A2, A3, C = x_shape
+    else:
+        b0, c0, A1, A2, A3 = x_shape
+        B, C = b0 * c0, 1
+    gx = torch.empty(tuple(x_shape), device=gy.device, dtype=torch.float32)
+    with torch.cuda.device(gy.device):
+        _lib.check(_lib.lib().wm_maxpool3d_bwd_f32(gy.data_ptr(), which.data_ptr(), gx.data_ptr(),
+                                                   B, A1, A2, A3, C, _stream()))
+    return gx
+
+
+class MaxPool3dFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, channels_last):
+        y, which = maxpool3d_forward(x, channels_last)
+        ctx.save_for_backward(which)
+        ctx.x_shape, ctx.channels_last = tuple(x.shape), channels_last
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (which,) = ctx.saved_tensors
+        return maxpool3d_backward(gy.contiguous(), which, ctx.x_shape, ctx.channels_last), None
+
+
+def maxpool3d(input, channels_last=True):
+    return MaxPool3dFunction.apply(input, channels_last)
+
+
 # --------------------------------------------------------------------------- least squares
 
 def gram(X, Y, acc=None):
