@@ -1,0 +1,109 @@
+"""GPU tests of the assembled Conv3D network (convolution.create_model) against a plain torch-CPU
+restatement with the same weights: forward, loss, every parameter gradient (1e-4 relative in
+max-norm: both sides are float32 end to end), training behaviour and the Keras-surface details."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from conftest import relinf  # noqa: E402
+from weather_model_amd import synth  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _cpu_forward(P, x1, x2, channels_last=True):
+    def pool(t):
+        if channels_last:       # window over axes 1..3, axis 4 untouched
+            return F.max_pool3d(t.permute(0, 4, 1, 2, 3), 2, 2).permute(0, 2, 3, 4, 1).contiguous()
+        return F.max_pool3d(t, 2, 2)
+
+    def branch(x, b):
+        for li in (1, 2):
+            x = pool(F.conv3d(x, P[f"{b}Conv3D{li}/kernel"], P[f"{b}Conv3D{li}/bias"]))
+        return x.reshape(x.shape[0], -1)
+    h = torch.cat((branch(x1, "1"), branch(x2, "2")), 1)
+    h = F.relu(F.linear(h, P["dense1/kernel"], P["dense1/bias"]))
+    return F.linear(h, P["output/kernel"], P["output/bias"])
+
+
+def _model():
+    from weather_model_amd.dropin import convolution as cv
+    cv = importlib.reload(cv)
+    return cv, cv.compile_model(cv.create_model((1, 20, 20, 20)))
+
+
+def test_model_shapes_follow_survey_2b():
+    cv, m = _model()
+    shapes = {k: tuple(v.shape) for k, v in m.params.items()}
+    assert shapes["1Conv3D1/kernel"] == (32, 1, 7, 7, 7)
+    assert shapes["2Conv3D2/kernel"] == (64, 16, 5, 5, 5)      # 16 = 32 // 2 after the quirky pool
+    assert shapes["dense1/kernel"] == (640, 640) and shapes["output/kernel"] == (8000, 640)
+    assert m.metrics_names == ["loss", "mae", "msle"]
+    w = m.get_weights()
+    assert w[0].shape == (7, 7, 7, 1, 32) and w[-2].shape == (640, 8000)
+    x = synth.uniform(1, (3, 1, 20, 20, 20))
+    before = m.predict([x, x])
+    assert before.shape == (3, 8000) and before.dtype == np.float32
+    m2 = cv.create_model((1, 20, 20, 20))
+    m2.set_weights(w)
+    np.testing.assert_array_equal(m2.predict([x, x]), before)
+
+
+@pytest.mark.parametrize("channels_last", [True, False])
+def test_forward_and_gradients_match_torch_cpu(channels_last):
+    from weather_model_amd.dropin._conv3d_model import Conv3DModel
+    m = Conv3DModel((1, 20, 20, 20), seed=3, pool_channels_last=channels_last)
+    m.compile()
+    with torch.no_grad():                      # non-zero biases so their gradients are exercised
+        for k, v in m.params.items():
+            if k.endswith("bias"):
+                v.copy_(torch.from_numpy(synth.uniform(hash(k) % 1000, tuple(v.shape), -0.1, 0.1)))
+    B = 4
+    x1 = synth.uniform(21, (B, 1, 20, 20, 20))
+    x2 = synth.uniform(22, (B, 1, 20, 20, 20))
+    y = synth.uniform(23, (B, 1, 8000))
+    P = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.params.items()}
+    ref = _cpu_forward(P, torch.from_numpy(x1), torch.from_numpy(x2), channels_last)
+    got = m([x1, x2], training=True)
+    assert relinf(got.detach().cpu().numpy(), ref.detach().numpy()) < 1e-4
+    yt = torch.from_numpy(y)
+    ref_loss = ((yt - ref) ** 2).mean()        # (B,1,P) - (B,P) broadcasts to (B,B,P)
+    assert ((yt - ref) ** 2).shape == (B, B, 8000)
+    loss = m.loss_fn(got, yt.cuda())
+    assert float(loss) == pytest.approx(float(ref_loss), rel=1e-5)
+    ref_loss.backward()
+    loss.backward()
+    for k, v in m.params.items():
+        assert relinf(v.grad.cpu().numpy(), P[k].grad.numpy()) < 1e-4, k
+
+
+def test_training_reduces_loss_and_early_stopping():
+    cv, m = _model()
+    m.broadcast_targets = False
+    rng = np.random.default_rng(0)
+    base = rng.uniform(0.3, 0.7, size=(1, 20, 20, 20)).astype(np.float32)
+
+    def gen():
+        while True:
+            a = base[None] + 0.05 * rng.standard_normal((8, 1, 20, 20, 20)).astype(np.float32)
+            b = base[None] + 0.05 * rng.standard_normal((8, 1, 20, 20, 20)).astype(np.float32)
+            yield a, b, (0.5 * (a + b)).reshape(8, 1, 8000)
+    h = m.fit(gen, epochs=4, steps_per_epoch=6, batch_size=8,
+              callbacks=[cv.EarlyStopping(monitor="loss", patience=2)], verbose=0)
+    assert h.epoch == list(range(len(h.history["loss"]))) and len(h.epoch) >= 2
+    assert h.history["loss"][-1] < h.history["loss"][0]
+    assert set(h.history) == {"loss", "mae", "msle"}
+
+    class Never:                                # a monitor that never improves stops after patience
+        monitor, patience = "loss", 1
+    h2 = m.fit(gen, epochs=6, steps_per_epoch=1, callbacks=[Never()], verbose=0)
+    assert 1 <= len(h2.epoch) <= 6
+    logs = m.test_step(next(gen()))
+    assert set(logs) == {"loss", "mae", "msle"}

@@ -1,0 +1,265 @@
+"""The Conv3D interpolation network of the reference's ``convolution.py`` (:156-180) on the GPU
+operators of libwm.so, behind the slice of the ``keras.Model`` surface that script uses.
+
+Per branch (two branches with their own weights, inputs ``start`` and ``end``):
+  Conv3D(32, 7, channels_first) -> MaxPool3D(2, 2) -> Conv3D(64, 5, channels_first) ->
+  MaxPool3D(2, 2) -> Flatten; then Concatenate -> Dense(relu) -> Dense(prod(input_shape)).
+The pools carry no ``data_format`` in the reference, so Keras pools in its default channels_last
+layout: on the (B,32,14,14,14) conv output the window runs over the (32,14,14) axes and the last
+axis is left alone -> (B,16,7,7,14); the second conv then sees 16 input channels.
+That is reproduced (``pool_channels_last=True``); ``False`` gives the presumably intended pool.
+
+Convolutions, pools and their gradients are the hand-written kernels (``ops.conv3d``,
+``ops.maxpool3d``); the two Dense layers are plain library GEMMs (``torch.nn.functional.linear`` =
+rocBLAS/hipBLASLt) and Adam is ``torch.optim.Adam`` with Keras' epsilon.  No CPU path.
+
+Parity: unpinned against the reference's own run (tensorflow/keras absent here); the operators are
+pinned against the float64 oracle and torch-CPU vectors, the assembled network against a plain
+torch restatement on CPU (tests/test_gpu_conv3d_model.py).
+"""
+from __future__ import annotations
+
+from math import prod
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from weather_model_amd import ops
+from ._keras_like import History, _MSLE_EPS, _batches
+
+
+def _glorot(shape, fan_in, fan_out, gen, device):
+    bound = (6.0 / (fan_in + fan_out)) ** 0.5          # keras glorot_uniform
+    t = torch.empty(shape, dtype=torch.float32)
+    t.uniform_(-bound, bound, generator=gen)
+    return t.to(device).requires_grad_(True)
+
+
+class Conv3DModel:
+    """``create_model(input_shape)`` of convolution.py; ``input_shape = (n_vars, Z, Y, X)``."""
+
+    CONV_SPECS = ((32, 7), (64, 5))                     # (filters, kernel side) (:164,166)
+
+    def __init__(self, input_shape, device=None, seed=0, pool_channels_last=True,
+                 broadcast_targets=True):
+        self.input_shape = tuple(int(v) for v in input_shape)
+        self.device = torch.device(device if device is not None else "cuda")
+        self.pool_channels_last = pool_channels_last
+        self.broadcast_targets = broadcast_targets
+        gen = torch.Generator().manual_seed(seed)
+        self.params: dict[str, torch.Tensor] = {}
+        shape = (1,) + self.input_shape                 # trace one sample through a branch
+        for branch in ("1", "2"):
+            cur = shape
+            for li, (filters, k) in enumerate(self.CONV_SPECS, start=1):
+                cin = cur[1]
+                fan_in, fan_out = cin * k ** 3, filters * k ** 3
+                name = f"{branch}Conv3D{li}"
+                self.params[name + "/kernel"] = _glorot((filters, cin, k, k, k), fan_in, fan_out,
+                                                        gen, self.device)
+                self.params[name + "/bias"] = torch.zeros((filters,), device=self.device,
+                                                          requires_grad=True)
+                cur = (1, filters) + tuple(d - k + 1 for d in cur[2:])
+                if min(cur[2:]) < 1:
+                    raise ValueError(f"input {self.input_shape} too small for kernel {k}")
+                cur = self._pooled_shape(cur)
+            flat = prod(cur[1:])
+        self.flat = 2 * flat
+        self.out_dim = prod(self.input_shape)
+        self.params["dense1/kernel"] = _glorot((self.flat, self.flat), self.flat, self.flat, gen,
+                                               self.device)
+        self.params["dense1/bias"] = torch.zeros((self.flat,), device=self.device,
+                                                 requires_grad=True)
+        self.params["output/kernel"] = _glorot((self.out_dim, self.flat), self.flat, self.out_dim,
+                                               gen, self.device)
+        self.params["output/bias"] = torch.zeros((self.out_dim,), device=self.device,
+                                                 requires_grad=True)
+        self.optimizer = None
+        self._metric_keys: list[str] = []
+        self.metrics_names = ["loss"]
+        self.stop_training = False
+
+    def _pooled_shape(self, s):
+        if self.pool_channels_last:
+            return (s[0], s[1] // 2, s[2] // 2, s[3] // 2, s[4])
+        return (s[0], s[1], s[2] // 2, s[3] // 2, s[4] // 2)
+
+    # ------------------------------------------------------------------ forward
+    def _branch(self, x, branch):
+        for li in (1, 2):
+            name = f"{branch}Conv3D{li}"
+            x = ops.conv3d(x, self.params[name + "/kernel"], self.params[name + "/bias"])
+            x = ops.maxpool3d(x, self.pool_channels_last)
+        return x.reshape(x.shape[0], -1)
+
+    def forward(self, x1, x2):
+        h = torch.cat((self._branch(x1, "1"), self._branch(x2, "2")), dim=1)
+        h = F.relu(F.linear(h, self.params["dense1/kernel"], self.params["dense1/bias"]))
+        return F.linear(h, self.params["output/kernel"], self.params["output/bias"])
+
+    def _to_dev(self, a):
+        t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a, np.float32))
+        t = t.to(self.device, torch.float32)
+        want = (t.shape[0],) + self.input_shape
+        if tuple(t.shape) != want:
+            raise ValueError(f"input has shape {tuple(t.shape)}, model takes {want}")
+        return t.contiguous()
+
+    def __call__(self, inputs, training=False):
+        x1, x2 = inputs
+        if training:
+            return self.forward(self._to_dev(x1), self._to_dev(x2))
+        with torch.no_grad():
+            return self.forward(self._to_dev(x1), self._to_dev(x2))
+
+    def predict(self, x, batch_size=None, verbose=0, **kwargs):
+        """``model.predict([data1, data2])`` -> (B, prod(input_shape)) float32 (:233)."""
+        return self(x).cpu().numpy()
+
+    # ------------------------------------------------------------------ training
+    def compile(self, optimizer="adam", loss=None, metrics=None, weighted_metrics=None, **kwargs):
+        name = loss if isinstance(loss, str) or loss is None else getattr(loss, "__name__", "")
+        if name not in (None, "mean_squared_error", "mse"):
+            raise ValueError(f"only mean_squared_error is implemented (got {name!r})")
+        if optimizer not in ("adam", "Adam") and not isinstance(optimizer, torch.optim.Optimizer):
+            raise ValueError("optimizer must be 'adam' or a torch optimizer over model.params")
+        self.optimizer = optimizer if isinstance(optimizer, torch.optim.Optimizer) else \
+            torch.optim.Adam(list(self.params.values()), lr=1e-3, betas=(0.9, 0.999), eps=1e-7)
+        keys = []
+        for m in list(metrics or []) + list(weighted_metrics or []):
+            m = {"mean_absolute_error": "mae", "mean_squared_logarithmic_error": "msle"}.get(m, m)
+            if m not in ("mae", "msle"):
+                raise ValueError(f"unsupported metric {m!r}")
+            keys.append(m)
+        self._metric_keys = keys
+        self.metrics_names = ["loss"] + keys
+
+    def _targets(self, y):
+        t = y if isinstance(y, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(y, np.float32))
+        return t.to(self.device, torch.float32)
+
+    def loss_fn(self, pred, y):
+        """keras.losses.mean_squared_error as the reference reaches it: targets arrive as
+        (B, n_vars, prod(Z,Y,X)) (:137,214) against predictions (B, P), so the subtraction
+        broadcasts to (B, B, P) when n_vars == 1 -- every prediction is scored against every
+        target of the batch.  ``broadcast_targets=False`` flattens the targets to (B, P)."""
+        if y.dim() == 3 and self.broadcast_targets:
+            return ((y - pred) ** 2).mean()
+        return ((y.reshape(pred.shape[0], -1) - pred) ** 2).mean()
+
+    def _batch_metrics(self, pred, y):
+        out = {}
+        yy = y if (y.dim() == 3 and self.broadcast_targets) else y.reshape(pred.shape[0], -1)
+        if "mae" in self._metric_keys:
+            out["mae"] = float((yy - pred).abs().mean())
+        if "msle" in self._metric_keys:
+            e = torch.log1p(pred.clamp_min(_MSLE_EPS)) - torch.log1p(yy.clamp_min(_MSLE_EPS))
+            out["msle"] = float((e * e).mean())
+        return out
+
+    def train_step(self, data):
+        """One optimizer step on a batch (x1, x2, y) (convolution.py:46-62)."""
+        if self.optimizer is None:
+            raise RuntimeError("compile the model before training")
+        x1, x2, y = data
+        y = self._targets(y)
+        self.optimizer.zero_grad(set_to_none=True)
+        pred = self.forward(self._to_dev(x1), self._to_dev(x2))
+        loss = self.loss_fn(pred, y)
+        loss.backward()
+        self.optimizer.step()
+        logs = {"loss": float(loss.detach())}
+        with torch.no_grad():
+            logs.update(self._batch_metrics(pred.detach(), y))
+        return logs
+
+    def test_step(self, data):
+        x1, x2, y = data
+        y = self._targets(y)
+        with torch.no_grad():
+            pred = self.forward(self._to_dev(x1), self._to_dev(x2))
+            logs = {"loss": float(self.loss_fn(pred, y))}
+            logs.update(self._batch_metrics(pred, y))
+        return logs
+
+    def fit(self, x=None, y=None, batch_size=None, epochs=1, verbose=1, callbacks=None,
+            validation_data=None, steps_per_epoch=None, validation_steps=None, **kwargs):
+        """Iterative Adam training, ``epochs`` x ``steps_per_epoch`` batches (:220-227);
+        ``EarlyStopping(monitor=, patience=)`` callbacks are honoured."""
+        source = (x[0], x[1], y) if y is not None else x
+        it = None
+        if callable(source) or hasattr(source, "__next__"):
+            if steps_per_epoch is None:
+                raise ValueError("steps_per_epoch is required for a generator source")
+            it = source() if callable(source) else source
+        hist = History(self)
+        stoppers = [c for c in (callbacks or []) if hasattr(c, "patience")]
+        best = {id(c): (float("inf"), 0) for c in stoppers}
+        for epoch in range(int(epochs)):
+            sums, count = {}, 0
+            batches = (next(it) for _ in range(int(steps_per_epoch))) if it is not None \
+                else _batches(source, steps_per_epoch)
+            for batch in batches:
+                for k, v in self.train_step(batch).items():
+                    sums[k] = sums.get(k, 0.0) + v
+                count += 1
+            logs = {k: v / max(count, 1) for k, v in sums.items()}
+            if validation_data is not None:
+                vs, vc = {}, 0
+                for batch in _batches(validation_data, validation_steps):
+                    for k, v in self.test_step(batch).items():
+                        vs["val_" + k] = vs.get("val_" + k, 0.0) + v
+                    vc += 1
+                logs.update({k: v / max(vc, 1) for k, v in vs.items()})
+            for k, v in logs.items():
+                hist.history.setdefault(k, []).append(v)
+            hist.epoch.append(epoch)
+            if verbose:
+                print(f"Epoch {epoch + 1}/{epochs} - " +
+                      " - ".join(f"{k}: {v:.6g}" for k, v in logs.items()))
+            stop = False
+            for c in stoppers:
+                cur = logs.get(c.monitor)
+                if cur is None:
+                    continue
+                b, wait = best[id(c)]
+                b, wait = (cur, 0) if cur < b else (b, wait + 1)
+                best[id(c)] = (b, wait)
+                stop = stop or wait >= c.patience
+            if stop:
+                break
+        self.history = hist
+        return hist
+
+    # ------------------------------------------------------------------ weights
+    LAYER_ORDER = ("1Conv3D1", "1Conv3D2", "2Conv3D1", "2Conv3D2", "dense1", "output")
+
+    def get_weights(self):
+        """[kernel, bias] per layer in creation order, in Keras layouts: conv kernels
+        (kD,kH,kW,Cin,Cout), dense kernels (in, out)."""
+        out = []
+        for name in self.LAYER_ORDER:
+            k = self.params[name + "/kernel"].detach()
+            k = k.permute(2, 3, 4, 1, 0) if k.dim() == 5 else k.t()
+            out += [k.contiguous().cpu().numpy(), self.params[name + "/bias"].detach().cpu().numpy()]
+        return out
+
+    def set_weights(self, weights):
+        if len(weights) != 2 * len(self.LAYER_ORDER):
+            raise ValueError(f"expected {2 * len(self.LAYER_ORDER)} arrays")
+        with torch.no_grad():
+            for i, name in enumerate(self.LAYER_ORDER):
+                k = torch.from_numpy(np.asarray(weights[2 * i], np.float32))
+                k = k.permute(4, 3, 0, 1, 2) if k.dim() == 5 else k.t()
+                self.params[name + "/kernel"].copy_(k.contiguous())
+                self.params[name + "/bias"].copy_(torch.from_numpy(np.asarray(weights[2 * i + 1],
+                                                                              np.float32)))
+
+    def count_params(self):
+        return sum(p.numel() for p in self.params.values())
+
+    def summary(self, print_fn=print):
+        for name in self.LAYER_ORDER:
+            print_fn(f"{name:10s} kernel {tuple(self.params[name + '/kernel'].shape)}")
+        print_fn(f"total parameters: {self.count_params()}")

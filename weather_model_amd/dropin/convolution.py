@@ -1,0 +1,175 @@
+"""Drop-in mirror of the reference's ``convolution.py``: the Conv3D
+interpolation network on 20^3 cubes.
+
+Same module-level names, signatures and array shapes as /root/reference/convolution.py.  The Keras
+functional model (:156-180) is ``_conv3d_model.Conv3DModel`` -- Conv3D / MaxPool3D forward and
+backward in the hand-written gfx950 kernels of libwm.so.  ``xarray`` is imported on first use
+(tests assign the module attribute ``xr``).
+
+Kept from the reference, and named: the pools run channels_last on channels_first tensors
+(:165,167 -- SURVEY 2b); targets are (B, n_vars, 8000) against predictions (B, 8000), which
+broadcasts inside the MSE (:137,214); ``DataGenerator`` draws its positions with ``random`` and
+strides ``time`` by 4 / 2 (:129-130); ``get_prediction_data`` reads the corner cube (:192-198).
+"""
+from __future__ import annotations
+
+import glob
+import os
+import random
+from math import prod
+
+import numpy as np
+
+from ._conv3d_model import Conv3DModel
+from ._keras_like import EarlyStopping
+
+DATA_PATH = "D:/Documents/Code/research/wrfout"
+ALL_FILES = [os.path.basename(f) for f in glob.glob(DATA_PATH + "/wrfout*")][:10]
+INPUT_SHAPE = (20, 20, 20)     # subset of the larger field processed at a time (:12)
+BATCH_SIZE = 16
+DATA_VARIABLES = ['T']
+
+DATA_VARS_MIN = {'T': -8.417083740234375, 'P': -50.28515625, 'PB': 5420.28076171875,
+                 'QVAPOR': 0.0, 'QRAIN': -1.3538986555136634e-12,
+                 'QSNOW': -3.2677986886402296e-15, 'QGRAUP': 0.0, 'U': -14.949191093444824,
+                 'V': -28.35787010192871, 'W': -5.611952781677246,
+                 'QCLOUD': -7.121892919154105e-12}
+DATA_VARS_MAX = {'T': 192.04437255859375, 'P': 1313.625, 'PB': 97532.5546875,
+                 'QVAPOR': 0.02198491431772709, 'QRAIN': 0.0021312725730240345,
+                 'QSNOW': 0.0001476061879657209, 'QGRAUP': 0.0, 'U': 26.568021774291992,
+                 'V': 17.940385818481445, 'W': 8.062047958374023,
+                 'QCLOUD': 0.002458590315654874}
+
+xr = None
+
+
+def _xr():
+    global xr
+    if xr is None:
+        import xarray
+        xr = xarray
+    return xr
+
+
+class CustomModel(Conv3DModel):
+    """Counterpart of the reference's ``keras.Model`` subclass (:44-77): ``train_step`` and
+    ``test_step`` take ``(x1, x2, y)`` batches."""
+
+
+def normalize(var, data) -> np.ndarray:
+    """min-max scaling; note the (var, data) argument order of this module (:80-82)."""
+    return (data.to_numpy() - DATA_VARS_MIN[var]) / (DATA_VARS_MAX[var] - DATA_VARS_MIN[var])
+
+
+def append_to_array(array1, array2):
+    array2 = np.expand_dims(array2, axis=0)                                  # :86-90
+    if array1 is None:
+        return array2
+    return np.append(array1, array2, axis=0)
+
+
+def load_data():
+    """{var: ndarray (files, 1, Z, Y, X)} of normalised fields (:93-104)."""
+    print("\rLoading data...", end='')
+    fields = {var: [] for var in DATA_VARIABLES}
+    for i, name in enumerate(ALL_FILES):
+        ds = _xr().open_dataset(f"{DATA_PATH}/{name}")
+        print(f"\rLoading data {i}/{len(ALL_FILES)}", end='')
+        for var in DATA_VARIABLES:
+            fields[var].append(normalize(var, ds[var]))
+        ds.close()
+    print("\rLoading data complete")
+    return {var: (np.stack(v) if v else None) for var, v in fields.items()}
+
+
+class DataGenerator:
+    """Random INPUT_SHAPE cubes: x1 at time t, x2 at t+4, y at t+2, BATCH_SIZE per batch
+    (:107-153).  Shapes: x (B, n_vars, Z, Y, X), y (B, n_vars, Z*Y*X)."""
+
+    def __init__(self, data):
+        self.index = 0
+        self.data = data
+        first = self.data[DATA_VARIABLES[0]]
+        self.data_shape = (len(first) - 4,
+                           len(first[0][0]) - INPUT_SHAPE[2],
+                           len(first[0][0][0]) - INPUT_SHAPE[1],
+                           len(first[0][0][0][0]) - INPUT_SHAPE[0])
+
+    def __len__(self):
+        return prod(self.data_shape)
+
+    def __getitem__(self):
+        starts, ends, targets = [], [], []
+        n_t, n_z, n_y, n_x = self.data_shape
+        for _ in range(BATCH_SIZE):
+            column = self.index % n_x
+            row = (self.index // n_x) % n_y
+            height = (self.index // (n_x * n_y)) % n_z
+            time = (self.index // (n_x * n_y * n_z)) % n_t
+            starts.append(np.stack([self.get_batch(v, column, row, height, time)
+                                    for v in DATA_VARIABLES]))
+            ends.append(np.stack([self.get_batch(v, column, row, height, time + 4)
+                                  for v in DATA_VARIABLES]))
+            targets.append(np.stack([self.get_batch(v, column, row, height, time + 2)
+                                     for v in DATA_VARIABLES]))
+            self.index += random.randint(0, self.__len__() - 1)
+            self.index %= self.__len__()
+        batch_y = np.stack(targets)
+        return (np.stack(starts), np.stack(ends),
+                np.reshape(batch_y, (batch_y.shape[0], batch_y.shape[1], -1)))
+
+    def get_batch(self, var, column, row, height, time):
+        return self.data[var][time][0][height: height + INPUT_SHAPE[2],
+                                       row: row + INPUT_SHAPE[1],
+                                       column: column + INPUT_SHAPE[0]]
+
+    def __call__(self):
+        while True:
+            yield self.__getitem__()
+            self.index = random.randint(0, self.__len__() - 1)
+            self.index %= self.__len__()
+
+
+def create_model(input_shape):
+    """Two-branch Conv3D network over ``start`` / ``end`` cubes -> flat prediction (:156-180)."""
+    return CustomModel(input_shape)
+
+
+def compile_model(model):
+    model.compile(optimizer="adam", loss="mean_squared_error", weighted_metrics=["mae", "msle"])
+    return model                                                             # :183-189
+
+
+def get_prediction_data(data, var, time):
+    height, row, column = 0, 0, 0                                            # :192-198
+    return data[var][time][0][height: height + INPUT_SHAPE[2],
+                              row: row + INPUT_SHAPE[1],
+                              column: column + INPUT_SHAPE[0]]
+
+
+def main():
+    """Build, train 10 x 10 batches with early stopping, compare against the two-frame average
+    (:201-250)."""
+    model = compile_model(create_model((len(DATA_VARIABLES), *INPUT_SHAPE)))
+    data = load_data()
+    dataset = DataGenerator(data)
+    callback = EarlyStopping(monitor="loss", patience=2)
+    model.fit(dataset, epochs=10, steps_per_epoch=10, batch_size=BATCH_SIZE,
+              callbacks=[callback], verbose=1)
+
+    data1 = np.expand_dims([get_prediction_data(data, DATA_VARIABLES[0], 0)], axis=0)
+    data2 = np.expand_dims([get_prediction_data(data, DATA_VARIABLES[0], 4)], axis=0)
+    actual_data = get_prediction_data(data, DATA_VARIABLES[0], 2)
+    prediction = model.predict([data1, data2]).reshape(INPUT_SHAPE)
+    average = (data1 + data2) / 2
+    rows = (("Average error", np.mean(abs(average - actual_data))),
+            ("Prediction error", np.mean(abs(prediction - actual_data))),
+            ("Average max error", np.max(abs(average - actual_data))),
+            ("Prediction max error", np.max(abs(prediction - actual_data))),
+            ("Average min error", np.min(abs(average - actual_data))),
+            ("Prediction min error", np.min(abs(prediction - actual_data))))
+    print("".join(f"{k}: {v}\n" for k, v in rows))
+
+
+if __name__ == "__main__":
+    main()
