@@ -59,7 +59,17 @@ constexpr int L_DO = L_DU + 64 * SP;         // [16][SP]  out, then dL/dout (row
 constexpr int L_E2 = L_DO + 16 * SP;         // [16][SP]  row 0 = 1, rest 0
 constexpr int L_AUX = L_E2 + 16 * SP;        // [3 layers][2][32]  sum_c W[o,c,0], sum_c W[o,c,2]
 constexpr int L_RED = L_AUX + 192;           // [WAVES] loss partials
-constexpr int L_TOTAL = L_RED + 16;
+// packed MFMA A operands (64 floats per operand, indexed by lane), filled once per workgroup
+constexpr int W_C1F = L_RED + 16;              // conv1: 1 operand
+constexpr int W_C2F = W_C1F + 64;              // conv2 fwd: 2 o-tiles x (1 + 4) steps
+constexpr int W_C3F = W_C2F + 2 * 5 * 64;      // conv3 fwd: 2 x (1 + 8)
+constexpr int W_C4F = W_C3F + 2 * 9 * 64;
+constexpr int W_C4B = W_C4F + 2 * 9 * 64;      // conv4 bwd data: 2 c-tiles x 8 steps
+constexpr int W_C3B = W_C4B + 2 * 8 * 64;
+constexpr int W_C2B = W_C3B + 2 * 8 * 64;      // conv2 bwd data: 1 c-tile x 8
+constexpr int W_L2F = W_C2B + 8 * 64;          // linear2 fwd: 16 steps
+constexpr int W_L2B = W_L2F + 16 * 64;         // dT: 4 j-tiles x 2 steps
+constexpr int L_TOTAL = W_L2B + 8 * 64;
 constexpr size_t LDS_BYTES = (size_t)L_TOTAL * sizeof(float);
 
 __device__ __forceinline__ f32x4 mma(float a, float b, f32x4 c)
@@ -77,26 +87,23 @@ __device__ __forceinline__ void put_tile(float *dst, int stride, int row0, int c
 
 // forward conv layer: Hout[o][n] = relu(b[o] + as[o] s[n] + ae[o] e[n] + sum_c Wm[o][c] Hin[c][n])
 // K = Cin (0 for conv1), O = Cout; weight element (o,c) sits at wbase[(o*K + c)*3 + 1].
+// Packed operands (LDS, wp): per o-tile 1 + K/4 operands; operand 0 = [b, as, ae, 0] by lane group.
 template <int K, int O>
-__device__ __forceinline__ void conv_fwd_layer(float *lds, const float *__restrict__ wmid,
-                                               const float *__restrict__ bias,
-                                               const float *as, const float *ae, int hin, int hout,
-                                               int wave, int i, int g)
+__device__ __forceinline__ void conv_fwd_layer(float *lds, int wp, int hin, int hout, int wave,
+                                               int lane, int i, int g)
 {
     constexpr int UNITS = (O / 16) * 6;
+    constexpr int STEPS = K / 4 + 1;
     for (int u = wave; u < UNITS; u += WAVES) {
-        const int o0 = (u / 6) * 16, c0 = (u % 6) * 16;
-        const int o = o0 + i;
+        const int ot = u / 6, o0 = ot * 16, c0 = (u % 6) * 16;
+        const float *a = lds + wp + ot * STEPS * 64 + lane;
         // rank-1 terms and bias as one MFMA step: A = [b, as, ae, 0], B = [1, s, e, 0]
-        const float a0 = g == 0 ? bias[o] : (g == 1 ? as[o] : (g == 2 ? ae[o] : 0.0f));
         const float b0 = lds[L_EE + g * NP + c0 + i];   // EE rows 0..3 = 1, s, e, 0
-        f32x4 acc = mma(a0, b0, (f32x4){0.f, 0.f, 0.f, 0.f});
-        if constexpr (K > 0) {
-#pragma unroll 4
-            for (int t = 0; t < K / 4; ++t) {
-                const int k = t + (K / 4) * g;
-                acc = mma(wmid[(o * K + k) * 3 + 1], lds[hin + k * NP + c0 + i], acc);
-            }
+        f32x4 acc = mma(a[0], b0, (f32x4){0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+        for (int t = 0; t < K / 4; ++t) {
+            const int k = t + (K / 4) * g;
+            acc = mma(a[(t + 1) * 64], lds[hin + k * NP + c0 + i], acc);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] = fmaxf(acc[r], 0.0f);
@@ -106,19 +113,18 @@ __device__ __forceinline__ void conv_fwd_layer(float *lds, const float *__restri
 
 // backward-data of a conv layer: dZin[c][n] = relu'(Hin[c][n]) * sum_o Wm[o][c] dZout[o][n]
 template <int K, int O>   // K = Cin (rows produced), O = Cout (contraction)
-__device__ __forceinline__ void conv_bwd_data_layer(float *lds, const float *__restrict__ wmid,
-                                                    int zout, int hin, int zin, int wave, int i,
-                                                    int g)
+__device__ __forceinline__ void conv_bwd_data_layer(float *lds, int wp, int zout, int hin, int zin,
+                                                    int wave, int lane, int i, int g)
 {
     constexpr int UNITS = (K / 16) * 6;
     for (int u = wave; u < UNITS; u += WAVES) {
-        const int c0 = (u / 6) * 16, n0 = (u % 6) * 16;
-        const int c = c0 + i;
+        const int ct = u / 6, c0 = ct * 16, n0 = (u % 6) * 16;
+        const float *a = lds + wp + ct * (O / 4) * 64 + lane;
         f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
+#pragma unroll
         for (int t = 0; t < O / 4; ++t) {
             const int o = t + (O / 4) * g;
-            acc = mma(wmid[(o * K + c) * 3 + 1], lds[zout + o * NP + n0 + i], acc);
+            acc = mma(a[t * 64], lds[zout + o * NP + n0 + i], acc);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -126,6 +132,36 @@ __device__ __forceinline__ void conv_bwd_data_layer(float *lds, const float *__r
             acc[r] = hv > 0.0f ? acc[r] : 0.0f;
         }
         put_tile(lds + zin, NP, c0, n0, acc, i, g);
+    }
+}
+
+// fill the packed operands of a forward conv layer (see conv_fwd_layer)
+template <int K>
+__device__ __forceinline__ void pack_conv_fwd(float *lds, int wp, const float *__restrict__ wmid,
+                                              const float *__restrict__ bias, int aux, int tid)
+{
+    constexpr int STEPS = K / 4 + 1;
+    for (int e = tid; e < 2 * STEPS * 64; e += THREADS) {
+        const int lane = e & 63, q = e >> 6, step = q % STEPS, ot = q / STEPS;
+        const int i = lane & 15, g = lane >> 4, o = ot * 16 + i;
+        float v;
+        if (step == 0)
+            v = g == 0 ? bias[o] : (g == 1 ? lds[aux + o] : (g == 2 ? lds[aux + 32 + o] : 0.0f));
+        else
+            v = wmid[(o * K + (step - 1) + (K / 4) * g) * 3 + 1];
+        lds[wp + e] = v;
+    }
+}
+
+// packed operands of a backward-data conv layer: [c-tile][step t] -> W[o = t + (O/4) g][c]
+template <int K, int O>
+__device__ __forceinline__ void pack_conv_bwd(float *lds, int wp, const float *__restrict__ wmid,
+                                              int tid)
+{
+    for (int e = tid; e < (K / 16) * (O / 4) * 64; e += THREADS) {
+        const int lane = e & 63, q = e >> 6, t = q % (O / 4), ct = q / (O / 4);
+        const int i = lane & 15, g = lane >> 4;
+        lds[wp + e] = wmid[((t + (O / 4) * g) * K + ct * 16 + i) * 3 + 1];
     }
 }
 
@@ -202,6 +238,30 @@ __global__ __launch_bounds__(THREADS) void model_kernel(
     for (int s = 0; s < SLOTS; ++s) gacc[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float loss_acc = 0.0f;
     __syncthreads();
+    // packed MFMA weight operands (the unit -> wave assignment is static, the weights are
+    // constant for the launch): read from global once per workgroup, from LDS per tile
+    if (tid < 64)
+        lds[W_C1F + tid] = g == 0 ? prm[P_C1B + i]
+                                  : (g == 1 ? prm[P_C1W + i * 2]
+                                            : (g == 2 ? prm[P_C1W + i * 2 + 1] : 0.0f));
+    pack_conv_fwd<16>(lds, W_C2F, prm + P_C2W, prm + P_C2B, L_AUX, tid);
+    pack_conv_fwd<32>(lds, W_C3F, prm + P_C3W, prm + P_C3B, L_AUX + 64, tid);
+    pack_conv_fwd<32>(lds, W_C4F, prm + P_C4W, prm + P_C4B, L_AUX + 128, tid);
+    for (int e = tid; e < 16 * 64; e += THREADS) {       // linear2 fwd: step t -> L2[i][t + 16 g]
+        const int l = e & 63, t = e >> 6, li = l & 15, lg = l >> 4;
+        lds[W_L2F + e] = li < 6 ? prm[P_L2W + li * 64 + t + 16 * lg] : 0.0f;
+    }
+    if constexpr (MODE != 0) {
+        pack_conv_bwd<32, 32>(lds, W_C4B, prm + P_C4W, tid);
+        pack_conv_bwd<32, 32>(lds, W_C3B, prm + P_C3W, tid);
+        pack_conv_bwd<16, 32>(lds, W_C2B, prm + P_C2W, tid);
+        for (int e = tid; e < 8 * 64; e += THREADS) {    // dT: [j-tile][t] -> L2[m = t + 2 g][j]
+            const int l = e & 63, q = e >> 6, t = q & 1, jt = q >> 1, li = l & 15, lg = l >> 4;
+            const int m = t + 2 * lg;
+            lds[W_L2B + e] = m < 6 ? prm[P_L2W + m * 64 + jt * 16 + li] : 0.0f;
+        }
+    }
+    __syncthreads();
 
     const long long ntiles = (B + TS - 1) / TS;
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -218,11 +278,10 @@ __global__ __launch_bounds__(THREADS) void model_kernel(
         // ---- forward
         // conv1 weight (16,1,2,1): as = W[o][0][0], ae = W[o][0][1]  (strided view)
         {
-            const float *w1 = prm + P_C1W;
             constexpr int UNITS = 6;
             for (int u = wave; u < UNITS; u += WAVES) {
-                const int c0 = u * 16, o = i;
-                const float a0 = g == 0 ? prm[P_C1B + o] : (g == 1 ? w1[o * 2] : (g == 2 ? w1[o * 2 + 1] : 0.0f));
+                const int c0 = u * 16;
+                const float a0 = lds[W_C1F + lane];
                 const float b0 = lds[L_EE + g * NP + c0 + i];
                 f32x4 acc = mma(a0, b0, (f32x4){0.f, 0.f, 0.f, 0.f});
 #pragma unroll
@@ -231,14 +290,11 @@ __global__ __launch_bounds__(THREADS) void model_kernel(
             }
         }
         __syncthreads();
-        conv_fwd_layer<16, 32>(lds, prm + P_C2W, prm + P_C2B, lds + L_AUX, lds + L_AUX + 32, L_H1,
-                               L_H2, wave, i, g);
+        conv_fwd_layer<16, 32>(lds, W_C2F, L_H1, L_H2, wave, lane, i, g);
         __syncthreads();
-        conv_fwd_layer<32, 32>(lds, prm + P_C3W, prm + P_C3B, lds + L_AUX + 64, lds + L_AUX + 96,
-                               L_H2, L_H3, wave, i, g);
+        conv_fwd_layer<32, 32>(lds, W_C3F, L_H2, L_H3, wave, lane, i, g);
         __syncthreads();
-        conv_fwd_layer<32, 32>(lds, prm + P_C4W, prm + P_C4B, lds + L_AUX + 128,
-                               lds + L_AUX + 160, L_H3, L_H4, wave, i, g);
+        conv_fwd_layer<32, 32>(lds, W_C4F, L_H3, L_H4, wave, lane, i, g);
         __syncthreads();
         // linear1: u[j][s] = sum_w sum_c L1[j][c*6+w] H4[c][w*16+s]; 8 units = 4 j-tiles x 2 w-halves
         {
@@ -264,12 +320,11 @@ __global__ __launch_bounds__(THREADS) void model_kernel(
         __syncthreads();
         // linear2: out[m][s] = bl2[m] + sum_j L2[m][j] T[j][s]   (one unit; rows m >= 6 are zero)
         if (wave == 0) {
-            const float *l2 = prm + P_L2W;
             f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
+#pragma unroll
             for (int t = 0; t < 16; ++t) {
                 const int j = t + 16 * g;
-                acc = mma(i < 6 ? l2[i * 64 + j] : 0.0f, lds[L_TT + j * SP + i], acc);
+                acc = mma(lds[W_L2F + t * 64 + lane], lds[L_TT + j * SP + i], acc);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -303,13 +358,11 @@ __global__ __launch_bounds__(THREADS) void model_kernel(
         // ---- backward (data path)
         // dT[j][s] = sum_m L2[m][j] dO[m][s];  dU = dT (1 - T^2): 4 units (j-tiles)
         if (wave < 4) {
-            const float *l2 = prm + P_L2W;
-            const int j = wave * 16 + i;
             f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int t = 0; t < 2; ++t) {           // m = 0..7 (rows >= 6 of dO are zero)
                 const int m = t + 2 * g;
-                acc = mma(m < 6 ? l2[m * 64 + j] : 0.0f, lds[L_DO + m * SP + i], acc);
+                acc = mma(lds[W_L2B + (wave * 2 + t) * 64 + lane], lds[L_DO + m * SP + i], acc);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -338,11 +391,11 @@ __global__ __launch_bounds__(THREADS) void model_kernel(
             put_tile(lds + L_Z4, NP, ct * 16, w * 16, acc, i, g);
         }
         __syncthreads();
-        conv_bwd_data_layer<32, 32>(lds, prm + P_C4W, L_Z4, L_H3, L_Z3, wave, i, g);
+        conv_bwd_data_layer<32, 32>(lds, W_C4B, L_Z4, L_H3, L_Z3, wave, lane, i, g);
         __syncthreads();
-        conv_bwd_data_layer<32, 32>(lds, prm + P_C3W, L_Z3, L_H2, L_Z2, wave, i, g);
+        conv_bwd_data_layer<32, 32>(lds, W_C3B, L_Z3, L_H2, L_Z2, wave, lane, i, g);
         __syncthreads();
-        conv_bwd_data_layer<16, 32>(lds, prm + P_C2W, L_Z2, L_H1, L_Z1, wave, i, g);
+        conv_bwd_data_layer<16, 32>(lds, W_C2B, L_Z2, L_H1, L_Z1, wave, lane, i, g);
         __syncthreads();
         // ---- weight gradients: every tile owned by one wave, accumulated in registers
 #pragma unroll
