@@ -263,6 +263,28 @@ __global__ __launch_bounds__(THREADS) void model_kernel(
     }
     __syncthreads();
 
+    // linear1 operands stay in registers: the forward unit of this wave (j-tile, w-half) and its
+    // three backward half-units (c-tile, w, j-half) never change
+    float l1f[24];
+    {
+        const int jt = wave >> 1, half = wave & 1, j = jt * 16 + i;
+#pragma unroll
+        for (int ww = 0; ww < 3; ++ww)
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+                l1f[ww * 8 + t] = prm[P_L1W + j * 192 + (t + 8 * g) * 6 + half * 3 + ww];
+    }
+    float l1b[24];
+    if constexpr (MODE != 0) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int h = wave + 8 * r, jh = h / 12, u = h % 12, ct = u / 6, w = u % 6;
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+                l1b[r * 8 + t] = prm[P_L1W + (8 * jh + t + 16 * g) * 192 + (ct * 16 + i) * 6 + w];
+        }
+    }
+
     const long long ntiles = (B + TS - 1) / TS;
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long long s0 = tile * TS;
@@ -299,14 +321,14 @@ __global__ __launch_bounds__(THREADS) void model_kernel(
         // linear1: u[j][s] = sum_w sum_c L1[j][c*6+w] H4[c][w*16+s]; 8 units = 4 j-tiles x 2 w-halves
         {
             const int jt = wave >> 1, half = wave & 1;
-            const float *l1 = prm + P_L1W;
-            const int j = jt * 16 + i;
             f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-            for (int w = half * 3; w < half * 3 + 3; ++w) {
-#pragma unroll 4
+#pragma unroll
+            for (int ww = 0; ww < 3; ++ww) {
+                const int w = half * 3 + ww;
+#pragma unroll
                 for (int t = 0; t < 8; ++t) {
                     const int c = t + 8 * g;
-                    acc = mma(l1[j * 192 + c * 6 + w], lds[L_H4 + c * NP + w * 16 + i], acc);
+                    acc = mma(l1f[ww * 8 + t], lds[L_H4 + c * NP + w * 16 + i], acc);
                 }
             }
             put_tile(lds + L_UU + half * 64 * SP, SP, jt * 16, 0, acc, i, g);
@@ -372,23 +394,23 @@ __global__ __launch_bounds__(THREADS) void model_kernel(
             put_tile(lds + L_DU, SP, wave * 16, 0, acc, i, g);
         }
         __syncthreads();
-        // dH4[c][w*16+s] = sum_j L1[j][c*6+w] dU[j][s];  dZ4 = dH4 * (H4 > 0): 12 units (ct, w)
-        for (int u = wave; u < 12; u += WAVES) {
-            const int ct = u / 6, w = u % 6;
-            const float *l1 = prm + P_L1W;
-            const int c = ct * 16 + i;
-            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-            for (int t = 0; t < 16; ++t) {
-                const int j = t + 16 * g;
-                acc = mma(l1[j * 192 + c * 6 + w], lds[L_DU + j * SP + i], acc);
-            }
+        // dH4[c][w*16+s] = sum_j L1[j][c*6+w] dU[j][s]: 24 half-units (c-tile, w, j-half), three
+        // per wave; the halves land in Z4 and (scratch) Z3 and are summed under the ReLU mask
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float hv = lds[L_H4 + (ct * 16 + 4 * g + r) * NP + w * 16 + i];
-                acc[r] = hv > 0.0f ? acc[r] : 0.0f;
+        for (int r = 0; r < 3; ++r) {
+            const int h = wave + 8 * r, jh = h / 12, u = h % 12, ct = u / 6, w = u % 6;
+            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int j = 8 * jh + t + 16 * g;
+                acc = mma(l1b[r * 8 + t], lds[L_DU + j * SP + i], acc);
             }
-            put_tile(lds + L_Z4, NP, ct * 16, w * 16, acc, i, g);
+            put_tile(lds + (jh ? L_Z3 : L_Z4), NP, ct * 16, w * 16, acc, i, g);
+        }
+        __syncthreads();
+        for (int e = tid; e < 32 * NC; e += THREADS) {
+            const int c = e / NC, n = e % NC, a = c * NP + n;
+            lds[L_Z4 + a] = lds[L_H4 + a] > 0.0f ? lds[L_Z4 + a] + lds[L_Z3 + a] : 0.0f;
         }
         __syncthreads();
         conv_bwd_data_layer<32, 32>(lds, W_C4B, L_Z4, L_H3, L_Z3, wave, lane, i, g);
