@@ -30,10 +30,16 @@ constexpr int TS = 16;          // samples per tile
 constexpr int NC = 6 * TS;      // columns per tile
 constexpr int NP = 98;          // LDS row stride of column-indexed arrays (conflict-free transposed reads)
 constexpr int SP = 18;          // LDS row stride of sample-indexed arrays
-constexpr int THREADS = 512;
+#ifndef WM_MODEL_THREADS
+#define WM_MODEL_THREADS 512
+#endif
+constexpr int THREADS = WM_MODEL_THREADS;
 constexpr int WAVES = THREADS / 64;
 constexpr int NTILES = 74;      // weight-gradient tiles
 constexpr int SLOTS = (NTILES + WAVES - 1) / WAVES;
+constexpr int L1F_R = 8 / WAVES;        // linear1 forward units (j-tile, w-half) per wave
+constexpr int L1B_R = 24 / WAVES;       // linear1 backward half-units per wave
+static_assert(WAVES == 8, "unit and gradient-tile assignment is written for 8 waves");
 constexpr int NPARAM = 20566;
 
 // flat parameter layout = PyTorch parameter order of the forward path
@@ -69,7 +75,9 @@ constexpr int W_C3B = W_C4B + 2 * 8 * 64;
 constexpr int W_C2B = W_C3B + 2 * 8 * 64;      // conv2 bwd data: 1 c-tile x 8
 constexpr int W_L2F = W_C2B + 8 * 64;          // linear2 fwd: 16 steps
 constexpr int W_L2B = W_L2F + 16 * 64;         // dT: 4 j-tiles x 2 steps
-constexpr int L_TOTAL = W_L2B + 8 * 64;
+constexpr int L_B1 = W_L2B + 8 * 64;           // linear1 bias [64]
+constexpr int L_B2 = L_B1 + 64;                // linear2 bias [16] (rows >= 6 zero)
+constexpr int L_TOTAL = L_B2 + 16;
 constexpr size_t LDS_BYTES = (size_t)L_TOTAL * sizeof(float);
 
 __device__ __forceinline__ f32x4 mma(float a, float b, f32x4 c)
@@ -207,6 +215,18 @@ __device__ __forceinline__ GradTile grad_tile(int id)
     return t;
 }
 
+// Slot s of wave w -> weight-gradient tile id (or -1).  Tiles 0..16 run 24 MFMA steps per sample
+// tile, tiles 17..73 four: wave 0 takes three long tiles and two short ones, waves 1..7 two long
+// and up to eight short ones -- 76..80 steps each instead of 76..100 with a round-robin deal.
+__device__ __forceinline__ int grad_tile_of(int s, int w)
+{
+    if (s < 2) return s * 8 + w;
+    if (w == 0) return s == 2 ? 16 : (s < 5 ? 21 + s : -1);          // 16, 24, 25
+    if (s == 2) return 16 + w;                                        // 17..23
+    const int id = 26 + (s - 3) * 7 + (w - 1);
+    return id < NTILES ? id : -1;
+}
+
 // MODE 0: forward only.  MODE 1: forward + backward with dL/dout = 2 (out - y) * dscale (fused
 // MSE).  MODE 2: forward + backward with dL/dout given.
 template <int MODE>
@@ -247,6 +267,8 @@ __global__ __launch_bounds__(THREADS) void model_kernel(
     pack_conv_fwd<16>(lds, W_C2F, prm + P_C2W, prm + P_C2B, L_AUX, tid);
     pack_conv_fwd<32>(lds, W_C3F, prm + P_C3W, prm + P_C3B, L_AUX + 64, tid);
     pack_conv_fwd<32>(lds, W_C4F, prm + P_C4W, prm + P_C4B, L_AUX + 128, tid);
+    if (tid < 64) lds[L_B1 + tid] = prm[P_L1B + tid];
+    if (tid < 16) lds[L_B2 + tid] = tid < 6 ? prm[P_L2B + tid] : 0.0f;
     for (int e = tid; e < 16 * 64; e += THREADS) {       // linear2 fwd: step t -> L2[i][t + 16 g]
         const int l = e & 63, t = e >> 6, li = l & 15, lg = l >> 4;
         lds[W_L2F + e] = li < 6 ? prm[P_L2W + li * 64 + t + 16 * lg] : 0.0f;
@@ -265,20 +287,21 @@ __global__ __launch_bounds__(THREADS) void model_kernel(
 
     // linear1 operands stay in registers: the forward unit of this wave (j-tile, w-half) and its
     // three backward half-units (c-tile, w, j-half) never change
-    float l1f[24];
-    {
-        const int jt = wave >> 1, half = wave & 1, j = jt * 16 + i;
+    float l1f[L1F_R * 24];
+#pragma unroll
+    for (int r = 0; r < L1F_R; ++r) {
+        const int u = wave + WAVES * r, jt = u >> 1, half = u & 1, j = jt * 16 + i;
 #pragma unroll
         for (int ww = 0; ww < 3; ++ww)
 #pragma unroll
             for (int t = 0; t < 8; ++t)
-                l1f[ww * 8 + t] = prm[P_L1W + j * 192 + (t + 8 * g) * 6 + half * 3 + ww];
+                l1f[r * 24 + ww * 8 + t] = prm[P_L1W + j * 192 + (t + 8 * g) * 6 + half * 3 + ww];
     }
-    float l1b[24];
+    float l1b[L1B_R * 8];
     if constexpr (MODE != 0) {
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const int h = wave + 8 * r, jh = h / 12, u = h % 12, ct = u / 6, w = u % 6;
+        for (int r = 0; r < L1B_R; ++r) {
+            const int h = wave + WAVES * r, jh = h / 12, u = h % 12, ct = u / 6, w = u % 6;
 #pragma unroll
             for (int t = 0; t < 8; ++t)
                 l1b[r * 8 + t] = prm[P_L1W + (8 * jh + t + 16 * g) * 192 + (ct * 16 + i) * 6 + w];
@@ -286,15 +309,33 @@ __global__ __launch_bounds__(THREADS) void model_kernel(
     }
 
     const long long ntiles = (B + TS - 1) / TS;
+    // x of the NEXT tile is fetched while the current one is computed (one float per thread)
+    const int xr = tid / NC, xcol = tid % NC, xoff = xr * 6 + (xcol >> 4), xs = xcol & 15;
+    float xnext = 0.0f;
+    if (tid < 2 * NC && (long long)blockIdx.x < ntiles) {
+        const long long smp = (long long)blockIdx.x * TS + xs;
+        xnext = smp < B ? x[smp * 12 + xoff] : 0.0f;
+    }
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long long s0 = tile * TS;
-        // ---- load x: XS[r][w*16+s] = x[s][r][w]; EE rows 1,2 mirror it
+        // ---- x: XS[r][w*16+s] = x[s][r][w]; EE rows 1,2 mirror it
         if (tid < 2 * NC) {
-            const int r = tid / NC, col = tid % NC, w = col >> 4, s = col & 15;
-            const long long smp = s0 + s;
-            const float v = smp < B ? x[smp * 12 + r * 6 + w] : 0.0f;
-            lds[L_XS + r * NP + col] = v;
-            lds[L_EE + (1 + r) * NP + col] = v;
+            lds[L_XS + xr * NP + xcol] = xnext;
+            lds[L_EE + (1 + xr) * NP + xcol] = xnext;
+            const long long smp = (tile + gridDim.x) * TS + xs;
+            xnext = (tile + gridDim.x < ntiles && smp < B) ? x[smp * 12 + xoff] : 0.0f;
+        }
+        // targets (or upstream gradient) of this tile, consumed by wave 0 after linear2
+        float tgt[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (MODE != 0) {
+            if (wave == 0) {
+                const long long smp = s0 + i;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = 4 * g + r;
+                    if (m < 6 && smp < B) tgt[r] = MODE == 1 ? y[smp * 6 + m] : dout[smp * 6 + m];
+                }
+            }
         }
         __syncthreads();
         // ---- forward
@@ -319,8 +360,9 @@ __global__ __launch_bounds__(THREADS) void model_kernel(
         conv_fwd_layer<32, 32>(lds, W_C4F, L_H3, L_H4, wave, lane, i, g);
         __syncthreads();
         // linear1: u[j][s] = sum_w sum_c L1[j][c*6+w] H4[c][w*16+s]; 8 units = 4 j-tiles x 2 w-halves
-        {
-            const int jt = wave >> 1, half = wave & 1;
+#pragma unroll
+        for (int r = 0; r < L1F_R; ++r) {
+            const int u = wave + WAVES * r, jt = u >> 1, half = u & 1;
             f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ww = 0; ww < 3; ++ww) {
@@ -328,7 +370,7 @@ __global__ __launch_bounds__(THREADS) void model_kernel(
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
                     const int c = t + 8 * g;
-                    acc = mma(l1f[ww * 8 + t], lds[L_H4 + c * NP + w * 16 + i], acc);
+                    acc = mma(l1f[r * 24 + ww * 8 + t], lds[L_H4 + c * NP + w * 16 + i], acc);
                 }
             }
             put_tile(lds + L_UU + half * 64 * SP, SP, jt * 16, 0, acc, i, g);
@@ -336,7 +378,7 @@ __global__ __launch_bounds__(THREADS) void model_kernel(
         __syncthreads();
         for (int e = tid; e < 64 * TS; e += THREADS) {
             const int j = e >> 4, s = e & 15;
-            const float u = lds[L_UU + j * SP + s] + lds[L_UU + 64 * SP + j * SP + s] + prm[P_L1B + j];
+            const float u = lds[L_UU + j * SP + s] + lds[L_UU + 64 * SP + j * SP + s] + lds[L_B1 + j];
             lds[L_TT + j * SP + s] = tanhf(u);
         }
         __syncthreads();
@@ -354,18 +396,18 @@ __global__ __launch_bounds__(THREADS) void model_kernel(
                 const long long smp = s0 + i;
                 float o = 0.0f;
                 if (m < 6) {
-                    o = acc[r] + prm[P_L2B + m];
+                    o = acc[r] + lds[L_B2 + m];
                     if (smp < B) out[smp * 6 + m] = o;
                 }
                 if constexpr (MODE != 0) {
                     float d = 0.0f;
                     if (m < 6 && smp < B) {
                         if constexpr (MODE == 1) {
-                            const float diff = o - y[smp * 6 + m];
+                            const float diff = o - tgt[r];
                             loss_acc += diff * diff;
                             d = 2.0f * diff * dscale;
                         } else {
-                            d = dout[smp * 6 + m];
+                            d = tgt[r];
                         }
                     }
                     lds[L_DO + m * SP + i] = d;
@@ -397,8 +439,8 @@ __global__ __launch_bounds__(THREADS) void model_kernel(
         // dH4[c][w*16+s] = sum_j L1[j][c*6+w] dU[j][s]: 24 half-units (c-tile, w, j-half), three
         // per wave; the halves land in Z4 and (scratch) Z3 and are summed under the ReLU mask
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const int h = wave + 8 * r, jh = h / 12, u = h % 12, ct = u / 6, w = u % 6;
+        for (int r = 0; r < L1B_R; ++r) {
+            const int h = wave + WAVES * r, jh = h / 12, u = h % 12, ct = u / 6, w = u % 6;
             f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
@@ -422,8 +464,8 @@ __global__ __launch_bounds__(THREADS) void model_kernel(
         // ---- weight gradients: every tile owned by one wave, accumulated in registers
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
-            const int id = s * WAVES + wave;
-            if (id < NTILES) {
+            const int id = grad_tile_of(s, wave);
+            if (id >= 0) {
                 const GradTile t = grad_tile(id);
                 const float *ap = lds + t.a_off + i * t.a_stride + t.ka0 + g;
                 const float *bp = lds + t.b_off + i * t.b_stride + t.kb0 + g;
@@ -440,8 +482,8 @@ __global__ __launch_bounds__(THREADS) void model_kernel(
         // tile space out: [block][tile id][r*64 + lane]
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
-            const int id = s * WAVES + wave;
-            if (id < NTILES) {
+            const int id = grad_tile_of(s, wave);
+            if (id >= 0) {
                 float *dst = gtiles + ((size_t)blockIdx.x * NTILES + id) * 256;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dst[r * 64 + lane] = gacc[s][r];
