@@ -162,6 +162,35 @@ int    wm_adam_step_f32(float *params, const float *grads, float *m, float *v, i
                         int step, float lr, float beta1, float beta2, float eps, float grad_scale,
                         void *stream);
 
+/* ------------------------------------------------------------------ fields (8f next rows) */
+
+/* One pass over a float32 field: out[0..4] = min, max, sum, sum of squares, count of non-NaN
+ * elements (float64).  Replaces the per-file float(ds[var].max()/.min()/.mean()/.std()) of
+ * data.py:59-60,76-77 and multipleRegression.py:392-393,414-415: mean = sum/count,
+ * std = sqrt(sumsq/count - mean^2).  accumulate != 0 merges into the values already in `out`
+ * (running statistics over files).  x must be 16-byte aligned.  Fixed-order combine. */
+size_t wm_field_stats_workspace_bytes(int64_t n);
+int wm_field_stats_f32(const float *x, int64_t n, double *out, int accumulate,
+                       void *workspace, size_t workspace_bytes, void *stream);
+
+/* y[i] = (x[i] - offset) / divisor in float32 with a true division: bitwise what numpy computes for
+ * normalize ((data - lo) / (hi - lo), newConvolution.py:47-49, convolution.py:80-82,
+ * multipleRegression.py:190-192) and standardize ((data - mean) / std, :195-197) on float32 data.
+ * x and y 16-byte aligned; y may alias x. */
+int wm_affine_scale_f32(const float *x, float *y, int64_t n, float offset, float divisor,
+                        void *stream);
+
+/* The sample gather of CustomDataset.__getitem__ / gather_data (newConvolution.py:86-106) for B
+ * samples at once.  vol is (T,Z,Y,X,V) float32 (the V variables of a grid point contiguous).
+ * Sample index id (idx[b], or idx0 + b when idx is NULL) decodes against shape (St,Sz,Sy,Sx):
+ * column = id % Sx, row = id / Sx % Sy, height = id / (Sx Sy) % Sz,
+ * time = id / (Sx Sy Sz) % St + time_offset.  xout (B,2,V) = [vol[time], vol[time + d_end]],
+ * yout (B,V) = vol[time + d_mid]  (the reference uses d_mid = 3, d_end = 6). */
+int wm_gather_triplets_f32(const float *vol, const int64_t *idx, int64_t idx0, float *xout,
+                           float *yout, int64_t B, int V, int T, int Z, int Y, int X,
+                           int St, int Sz, int Sy, int Sx, int time_offset, int d_mid, int d_end,
+                           void *stream);
+
 /* ------------------------------------------------------------------ synthetic data ------ */
 
 /* Counter-based generator: element i of `out` depends only on (seed, offset + i).  Same hash as

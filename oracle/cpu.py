@@ -204,3 +204,33 @@ def lstsq(X, Y, fit_intercept=True):
         return np.linalg.lstsq(A, Y, rcond=None)[0]
     b = np.linalg.lstsq(X, Y, rcond=None)[0]
     return np.concatenate([b, np.zeros((1, Y.shape[1]))], axis=0)
+
+
+# ---------------------------------------------------------------------------------------------
+# fields (SURVEY 8f ranks 3, 4): numpy restatements of the reference's host arithmetic.
+
+def field_stats(x):
+    """[min, max, sum, sumsq, count] over the non-NaN elements, float64 (data.py:59-60,76-77 take
+    float(ds[var].max()/.min()/.mean()/.std()); xarray skips NaNs in float reductions)."""
+    v = np.asarray(x, dtype=np.float32).reshape(-1)
+    v = v[~np.isnan(v)].astype(np.float64)
+    return np.array([v.min(), v.max(), v.sum(), (v * v).sum(), float(v.size)])
+
+
+def affine_scale(x, offset, divisor):
+    """(data - lo) / (hi - lo) exactly as numpy evaluates it for a float32 array and Python-float
+    scalars (newConvolution.py:48): float32 subtraction and division."""
+    x = np.asarray(x, dtype=np.float32)
+    return (x - np.float32(offset)) / np.float32(divisor)
+
+
+def gather_triplets(vol, shape, indices, time_offset=0, d_mid=3, d_end=6):
+    """CustomDataset.__getitem__ (newConvolution.py:93-106) over a (T,Z,Y,X,V) volume."""
+    St, Sz, Sy, Sx = shape
+    idx = np.asarray(indices, dtype=np.int64) % (St * Sz * Sy * Sx)
+    column = idx % Sx
+    row = (idx // Sx) % Sy
+    height = (idx // (Sx * Sy)) % Sz
+    time = (idx // (Sx * Sy * Sz)) % St + time_offset
+    g = lambda t: vol[t, height, row, column]                       # noqa: E731
+    return np.stack((g(time), g(time + d_end)), axis=1), g(time + d_mid)

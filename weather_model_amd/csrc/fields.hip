@@ -1,0 +1,245 @@
+// fields.hip -- the steps either side of the hot path, all HBM-bound:
+//   * one-pass field statistics (min, max, sum, sum of squares, count) replacing the per-file
+//     xarray reductions of data.py:52-85 / multipleRegression.py:381-425,
+//   * element-wise normalise / standardise  (newConvolution.py:47-49, multipleRegression.py:190-197,
+//     convolution.py:80-82),
+//   * the sample gather of CustomDataset (newConvolution.py:86-106): flat index -> (time, height,
+//     row, column) decode and the (t, t+d_end ; t+d_mid) triplet gather from a resident volume.
+// Algorithmic bytes: stats 4 B/element (read once); normalise 8 B/element; gather 72 B read +
+// 72 B written per sample (6 variables).
+#include "common.h"
+
+namespace {
+
+constexpr int BLOCK = 256;
+constexpr int NSTAT = 5;      // min, max, sum, sumsq, count
+
+__device__ __forceinline__ void stat_add(float v, float &mn, float &mx, double &s, double &ss,
+                                         double &cnt)
+{
+    // NaNs are skipped, as xarray's reductions do by default (skipna for float data)
+    if (v == v) {
+        mn = fminf(mn, v);
+        mx = fmaxf(mx, v);
+        const double d = (double)v;
+        s += d;
+        ss = fma(d, d, ss);
+        cnt += 1.0;
+    }
+}
+
+// partial: [gridDim.x][NSTAT] float64
+__global__ __launch_bounds__(BLOCK) void field_stats_kernel(const float *__restrict__ x,
+                                                            long long n,
+                                                            double *__restrict__ partial)
+{
+    __shared__ double red[BLOCK / 64][NSTAT];
+    float mn = __builtin_inff(), mx = -__builtin_inff();
+    double s = 0.0, ss = 0.0, cnt = 0.0;
+    const long long n4 = n / 4;
+    const f32x4 *x4 = reinterpret_cast<const f32x4 *>(x);
+    const long long stride = (long long)gridDim.x * BLOCK;
+    long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    // two independent 16-byte loads in flight per thread
+    for (; i + stride < n4; i += 2 * stride) {
+        const f32x4 a = __builtin_nontemporal_load(x4 + i);
+        const f32x4 b = __builtin_nontemporal_load(x4 + i + stride);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) stat_add(a[e], mn, mx, s, ss, cnt);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) stat_add(b[e], mn, mx, s, ss, cnt);
+    }
+    for (; i < n4; i += stride) {
+        const f32x4 a = __builtin_nontemporal_load(x4 + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) stat_add(a[e], mn, mx, s, ss, cnt);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n - n4 * 4))
+        stat_add(x[n4 * 4 + threadIdx.x], mn, mx, s, ss, cnt);
+
+    double v[NSTAT] = {(double)mn, (double)mx, s, ss, cnt};
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        v[0] = fmin(v[0], __shfl_xor(v[0], o, 64));
+        v[1] = fmax(v[1], __shfl_xor(v[1], o, 64));
+        v[2] += __shfl_xor(v[2], o, 64);
+        v[3] += __shfl_xor(v[3], o, 64);
+        v[4] += __shfl_xor(v[4], o, 64);
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0)
+#pragma unroll
+        for (int k = 0; k < NSTAT; ++k) red[wv][k] = v[k];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r[NSTAT] = {red[0][0], red[0][1], red[0][2], red[0][3], red[0][4]};
+        for (int w = 1; w < BLOCK / 64; ++w) {
+            r[0] = fmin(r[0], red[w][0]);
+            r[1] = fmax(r[1], red[w][1]);
+            r[2] += red[w][2];
+            r[3] += red[w][3];
+            r[4] += red[w][4];
+        }
+#pragma unroll
+        for (int k = 0; k < NSTAT; ++k) partial[(size_t)blockIdx.x * NSTAT + k] = r[k];
+    }
+}
+
+// fixed-order combine of the block partials; merges into out when accumulate != 0
+__global__ __launch_bounds__(64) void field_stats_finalize_kernel(const double *__restrict__ partial,
+                                                                  int nparts,
+                                                                  double *__restrict__ out,
+                                                                  int accumulate)
+{
+    if (threadIdx.x != 0) return;
+    double r[NSTAT] = {__builtin_inf(), -__builtin_inf(), 0.0, 0.0, 0.0};
+    if (accumulate) {
+#pragma unroll
+        for (int k = 0; k < NSTAT; ++k) r[k] = out[k];
+    }
+    for (int p = 0; p < nparts; ++p) {
+        r[0] = fmin(r[0], partial[(size_t)p * NSTAT + 0]);
+        r[1] = fmax(r[1], partial[(size_t)p * NSTAT + 1]);
+        r[2] += partial[(size_t)p * NSTAT + 2];
+        r[3] += partial[(size_t)p * NSTAT + 3];
+        r[4] += partial[(size_t)p * NSTAT + 4];
+    }
+#pragma unroll
+    for (int k = 0; k < NSTAT; ++k) out[k] = r[k];
+}
+
+// y = (x - a) / d in float32, the arithmetic numpy performs on a float32 array with Python-float
+// scalars ((data - lo) / (hi - lo), newConvolution.py:48): true division, so results are bitwise
+// those of the reference.
+__global__ __launch_bounds__(BLOCK) void affine_scale_kernel(const float *__restrict__ x,
+                                                             float *__restrict__ y, long long n,
+                                                             float a, float d)
+{
+    const long long n4 = n / 4;
+    const f32x4 *x4 = reinterpret_cast<const f32x4 *>(x);
+    f32x4 *y4 = reinterpret_cast<f32x4 *>(y);
+    const long long stride = (long long)gridDim.x * BLOCK;
+    for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < n4; i += stride) {
+        f32x4 v = __builtin_nontemporal_load(x4 + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = __fdiv_rn(v[e] - a, d);
+        __builtin_nontemporal_store(v, y4 + i);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n - n4 * 4)) {
+        const long long i = n4 * 4 + threadIdx.x;
+        y[i] = __fdiv_rn(x[i] - a, d);
+    }
+}
+
+// vol: (T, Z, Y, X, V) float32, the V variables of a grid point contiguous.  Sample idx decodes as
+// CustomDataset.__getitem__ does (newConvolution.py:93-99) with shape = (St, Sz, Sy, Sx):
+//   column = idx % Sx, row = idx / Sx % Sy, height = idx / (Sx Sy) % Sz,
+//   time = idx / (Sx Sy Sz) % St + time_offset
+// xout[b] = [vol[time], vol[time + d_end]] (2 x V), yout[b] = vol[time + d_mid] (V).
+__global__ __launch_bounds__(BLOCK) void gather_triplets_kernel(
+    const float *__restrict__ vol, const long long *__restrict__ idx, long long idx0,
+    float *__restrict__ xout, float *__restrict__ yout, long long B, int V, int Z, int Y, int X,
+    int St, int Sz, int Sy, int Sx, int time_offset, int d_mid, int d_end)
+{
+    const long long total = B * V;
+    const long long plane = (long long)Z * Y * X * V;     // one time slice
+    const long long tot = (long long)St * Sz * Sy * Sx;
+    for (long long e = (long long)blockIdx.x * BLOCK + threadIdx.x; e < total;
+         e += (long long)gridDim.x * BLOCK) {
+        const long long b = e / V;
+        const int v = (int)(e - b * V);
+        long long id = idx ? idx[b] : idx0 + b;
+        id %= tot;                                        // Python-style modulo: any index decodes
+        if (id < 0) id += tot;                            // inside the sample shape
+        const int column = (int)(id % Sx);
+        const int row = (int)((id / Sx) % Sy);
+        const int height = (int)((id / ((long long)Sx * Sy)) % Sz);
+        const int time = (int)((id / ((long long)Sx * Sy * Sz)) % St) + time_offset;
+        const long long pos = (((long long)height * Y + row) * X + column) * V + v;
+        const float *p = vol + (long long)time * plane + pos;
+        xout[b * 2 * V + v] = p[0];
+        xout[b * 2 * V + V + v] = p[(long long)d_end * plane];
+        yout[b * V + v] = p[(long long)d_mid * plane];
+    }
+}
+
+int stream_grid(long long work_items)
+{
+    long long g = (work_items + BLOCK - 1) / BLOCK;
+    const long long cap = (long long)wm_num_cus() * 8;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+extern "C" size_t wm_field_stats_workspace_bytes(int64_t n)
+{
+    if (n < 0 || wm_num_cus() <= 0) return 0;
+    return wm_align_up((size_t)wm_num_cus() * 8 * NSTAT * sizeof(double), 256);
+}
+
+extern "C" int wm_field_stats_f32(const float *x, int64_t n, double *out, int accumulate,
+                                  void *workspace, size_t workspace_bytes, void *stream)
+{
+    WM_REQUIRE(x && out, WM_ERR_INVALID, "wm_field_stats_f32: null pointer");
+    WM_REQUIRE(n > 0, WM_ERR_INVALID, "wm_field_stats_f32: need at least one element (n=%lld)",
+               (long long)n);
+    WM_REQUIRE(((uintptr_t)x & 15) == 0, WM_ERR_INVALID,
+               "wm_field_stats_f32: x must be 16-byte aligned");
+    WM_REQUIRE(wm_num_cus() > 0, WM_ERR_NO_DEVICE, "wm_field_stats_f32: no HIP device");
+    const size_t need = wm_field_stats_workspace_bytes(n);
+    WM_REQUIRE(workspace && workspace_bytes >= need, WM_ERR_WORKSPACE,
+               "wm_field_stats_f32: workspace of %zu bytes needed, %zu given", need,
+               workspace_bytes);
+    const int grid = stream_grid((n / 4 + 1) / 2 + 1);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(field_stats_kernel, dim3(grid), dim3(BLOCK), 0, st, x, (long long)n,
+                       (double *)workspace);
+    WM_LAUNCH_CHECK("field_stats_kernel");
+    hipLaunchKernelGGL(field_stats_finalize_kernel, dim3(1), dim3(64), 0, st,
+                       (const double *)workspace, grid, out, accumulate);
+    WM_LAUNCH_CHECK("field_stats_finalize_kernel");
+    return WM_OK;
+}
+
+extern "C" int wm_affine_scale_f32(const float *x, float *y, int64_t n, float offset,
+                                   float divisor, void *stream)
+{
+    WM_REQUIRE(x && y, WM_ERR_INVALID, "wm_affine_scale_f32: null pointer");
+    WM_REQUIRE(n >= 0, WM_ERR_INVALID, "wm_affine_scale_f32: negative size");
+    WM_REQUIRE((((uintptr_t)x | (uintptr_t)y) & 15) == 0, WM_ERR_INVALID,
+               "wm_affine_scale_f32: x and y must be 16-byte aligned");
+    if (n == 0) return WM_OK;
+    WM_REQUIRE(wm_num_cus() > 0, WM_ERR_NO_DEVICE, "wm_affine_scale_f32: no HIP device");
+    hipLaunchKernelGGL(affine_scale_kernel, dim3(stream_grid(n / 4 + 1)), dim3(BLOCK), 0,
+                       (hipStream_t)stream, x, y, (long long)n, offset, divisor);
+    WM_LAUNCH_CHECK("affine_scale_kernel");
+    return WM_OK;
+}
+
+extern "C" int wm_gather_triplets_f32(const float *vol, const int64_t *idx, int64_t idx0,
+                                      float *xout, float *yout, int64_t B, int V, int T, int Z,
+                                      int Y, int X, int St, int Sz, int Sy, int Sx,
+                                      int time_offset, int d_mid, int d_end, void *stream)
+{
+    WM_REQUIRE(vol && xout && yout, WM_ERR_INVALID, "wm_gather_triplets_f32: null pointer");
+    WM_REQUIRE(B >= 0 && V > 0 && T > 0 && Z > 0 && Y > 0 && X > 0, WM_ERR_INVALID,
+               "wm_gather_triplets_f32: bad volume shape");
+    WM_REQUIRE(St > 0 && Sz > 0 && Sy > 0 && Sx > 0 && Sz <= Z && Sy <= Y && Sx <= X,
+               WM_ERR_INVALID, "wm_gather_triplets_f32: sample shape outside the volume");
+    WM_REQUIRE(time_offset >= 0 && d_mid >= 0 && d_end >= 0 &&
+                   time_offset + St - 1 + (d_end > d_mid ? d_end : d_mid) < T,
+               WM_ERR_INVALID,
+               "wm_gather_triplets_f32: time %d + %d steps + offset %d leaves the %d slices",
+               time_offset, St, d_end > d_mid ? d_end : d_mid, T);
+    WM_REQUIRE(idx || idx0 >= 0, WM_ERR_INVALID, "wm_gather_triplets_f32: negative first index");
+    if (B == 0) return WM_OK;
+    WM_REQUIRE(wm_num_cus() > 0, WM_ERR_NO_DEVICE, "wm_gather_triplets_f32: no HIP device");
+    hipLaunchKernelGGL(gather_triplets_kernel, dim3(stream_grid(B * V)), dim3(BLOCK), 0,
+                       (hipStream_t)stream, vol, (const long long *)idx, (long long)idx0, xout,
+                       yout, (long long)B, V, Z, Y, X, St, Sz, Sy, Sx, time_offset, d_mid, d_end);
+    WM_LAUNCH_CHECK("gather_triplets_kernel");
+    return WM_OK;
+}

@@ -113,11 +113,16 @@ class CustomDataset(Dataset):
         return torch.stack((start_x, end_x), dim=0), y
 
     def batch(self, indices, device=None):
-        """Vectorised gather of many items: x (B,2,6), y (B,6)."""
-        if self._vol is None or (device is not None and self._vol.device != torch.device(device)):
-            vol = torch.stack([self.data[var][:, 0] for var in data_vars], dim=-1)   # (T,Z,Y,X,6)
-            self._vol = vol.to(device) if device is not None else vol
+        """Many items at once: x (B,2,6), y (B,6).  The volume is laid out (T,Z,Y,X,6) once; on
+        the GPU the decode + triplet gather is one ``wm_gather_triplets_f32`` launch."""
+        want = None if device is None else torch.device(device)
+        if self._vol is None or (want is not None and self._vol.device.type != want.type):
+            vol = torch.stack([self.data[var][:, 0] for var in data_vars], dim=-1).float()
+            self._vol = (vol.to(want) if want is not None else vol).contiguous()
         idx = torch.as_tensor(indices, device=self._vol.device, dtype=torch.long)
+        if self._vol.is_cuda:
+            return ops.gather_triplets(self._vol, self.shape, indices=idx,
+                                       time_offset=self.time_offset)
         time, height, row, column = self._decode(idx)
         g = lambda t: self._vol[t, height, row, column]                                # noqa: E731
         return torch.stack((g(time), g(time + 6)), dim=1), g(time + 3)

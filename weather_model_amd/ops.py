@@ -369,6 +369,64 @@ def linear_predict(X, beta):
     return out
 
 
+# --------------------------------------------------------------------------- fields
+
+def field_stats(x, out=None):
+    """(min, max, sum, sumsq, count) of a float32 CUDA tensor as a float64 tensor of 5; passing the
+    previous ``out`` merges (running statistics over files)."""
+    x = _req(x, "field").reshape(-1)
+    if x.numel() == 0:
+        raise ValueError("field_stats of an empty field")
+    accumulate = out is not None
+    if out is None:
+        out = torch.empty((5,), device=x.device, dtype=torch.float64)
+    elif out.shape != (5,) or out.dtype != torch.float64 or not out.is_cuda:
+        raise ValueError("out must be a CUDA float64 tensor of 5")
+    L = _lib.lib()
+    with torch.cuda.device(x.device):
+        nbytes = L.wm_field_stats_workspace_bytes(x.numel())
+        ws = torch.empty((max(nbytes, 8),), device=x.device, dtype=torch.uint8)
+        _lib.check(L.wm_field_stats_f32(x.data_ptr(), x.numel(), out.data_ptr(), int(accumulate),
+                                        ws.data_ptr(), ws.numel(), _stream()))
+    return out
+
+
+def affine_scale(x, offset, divisor, out=None):
+    """(x - offset) / divisor in float32 (normalize / standardize of the reference)."""
+    x = _req(x, "field")
+    y = torch.empty_like(x) if out is None else _req(out, "out")
+    if y.shape != x.shape:
+        raise ValueError("out has a different shape")
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().wm_affine_scale_f32(x.data_ptr(), y.data_ptr(), x.numel(),
+                                                  float(offset), float(divisor), _stream()))
+    return y
+
+
+def gather_triplets(vol, shape, indices=None, first=0, count=None, time_offset=0, d_mid=3,
+                    d_end=6):
+    """x (B,2,V), y (B,V) for samples of a resident (T,Z,Y,X,V) volume; ``indices`` (int64 CUDA
+    tensor) or the contiguous range [first, first + count)."""
+    vol = _req(vol, "volume")
+    if vol.dim() != 5:
+        raise ValueError(f"volume must be (T,Z,Y,X,V), got {tuple(vol.shape)}")
+    T, Z, Y, X, V = vol.shape
+    St, Sz, Sy, Sx = (int(v) for v in shape)
+    if indices is not None:
+        indices = _req(indices, "indices", torch.int64).reshape(-1)
+        B = indices.numel()
+    else:
+        B = int(count)
+    xout = torch.empty((B, 2, V), device=vol.device, dtype=torch.float32)
+    yout = torch.empty((B, V), device=vol.device, dtype=torch.float32)
+    with torch.cuda.device(vol.device):
+        _lib.check(_lib.lib().wm_gather_triplets_f32(
+            vol.data_ptr(), 0 if indices is None else indices.data_ptr(), int(first),
+            xout.data_ptr(), yout.data_ptr(), B, V, T, Z, Y, X, St, Sz, Sy, Sx, int(time_offset),
+            int(d_mid), int(d_end), _stream()))
+    return xout, yout
+
+
 # --------------------------------------------------------------------------- synthetic data
 
 def synth_uniform(shape, seed, lo=0.0, hi=1.0, offset=0, device="cuda"):
