@@ -419,6 +419,8 @@ def gather_triplets(vol, shape, indices=None, first=0, count=None, time_offset=0
         B = int(count)
     xout = torch.empty((B, 2, V), device=vol.device, dtype=torch.float32)
     yout = torch.empty((B, V), device=vol.device, dtype=torch.float32)
+    if B == 0:
+        return xout, yout
     with torch.cuda.device(vol.device):
         _lib.check(_lib.lib().wm_gather_triplets_f32(
             vol.data_ptr(), 0 if indices is None else indices.data_ptr(), int(first),
