@@ -112,3 +112,28 @@ def test_dataset_batch_uses_the_gather_kernel():
     xs, ys = zip(*[ds[i] for i in idx])
     np.testing.assert_array_equal(xb.cpu().numpy(), torch.stack(xs).numpy())
     np.testing.assert_array_equal(yb.cpu().numpy(), torch.stack(ys).numpy())
+
+
+def test_data_module_statistics_on_device_match_host_path():
+    import importlib
+    import json
+    import sys
+    sys.path.insert(0, HERE)
+    import fakes
+    from weather_model_amd.dropin import data
+    data = importlib.reload(data)
+    with open(os.path.join(HERE, "golden", "data_golden.json")) as fh:
+        g = json.load(fh)
+    data.X_TRAIN_DATA_PATH = g["data_path"]
+    scale = {k: tuple(v) for k, v in g["scale"].items()}
+    files = {data.get_file_path(i, g["n_files"]):
+             fakes.wrf_like_file(g["seed0"] + i, g["vars"], tuple(g["shape"]), scale)
+             for i in range(g["n_files"])}
+    data.xr = fakes.FakeXarray(files)
+    data.DEVICE_STATS = True
+    lo, hi = data.calculate_data_range(g["n_files"])
+    mean, std = data.calculate_data_mean_std(g["n_files"])
+    for v in g["vars"]:
+        assert lo[v] == g["min"][v] and hi[v] == g["max"][v]          # exact
+        assert mean[v] == pytest.approx(g["mean"][v], rel=1e-5, abs=1e-6)
+        assert std[v] == pytest.approx(g["std"][v], rel=1e-5)

@@ -15,8 +15,12 @@ from __future__ import annotations
 import fnmatch
 import os
 
+from . import _fields
+
 DATA_VARS = ['T', 'P', 'PB', 'QVAPOR', 'QRAIN', 'QSNOW', 'QGRAUP', 'U', 'V', 'W', 'QCLOUD']  # :28-40
 X_TRAIN_DATA_PATH = 'D:/Documents/Code/research/wrfout'
+
+DEVICE_STATS = False    # True: per-file reductions run on the GPU (weather_model_amd.ops.field_stats)
 
 xr = None
 
@@ -35,7 +39,7 @@ def calculate_data_range(data_size):
     for i in range(data_size):
         ds = _xr().open_dataset(get_file_path(i, data_size))
         for data in DATA_VARS:
-            hi, lo = float(ds[data].max()), float(ds[data].min())
+            hi, lo = _fields.summary(ds[data], DEVICE_STATS)[:2]
             if data not in max_value or hi > max_value[data]:
                 max_value[data] = hi
             if data not in min_value or lo < min_value[data]:
@@ -55,8 +59,7 @@ def calculate_data_mean_std(data_size, exact=False):
     for i in range(data_size):
         ds = _xr().open_dataset(get_file_path(i, data_size))
         for data in DATA_VARS:
-            size = ds[data].size
-            m, s = float(ds[data].mean()), float(ds[data].std())
+            _, _, m, s, size = _fields.summary(ds[data], DEVICE_STATS)
             mean_value[data] = mean_value.get(data, 0) + m
             std_value[data] = std_value.get(data, 0) + (s ** 2) * size
             sizes[data] = sizes.get(data, 0) + size

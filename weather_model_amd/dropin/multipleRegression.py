@@ -24,6 +24,7 @@ from warnings import warn
 
 import numpy as np
 
+from . import _fields
 from ._keras_like import EarlyStopping, History, LinearStackModel  # noqa: F401
 
 X_TRAIN_DATA_PATH = 'D:/Documents/Code/research/wrfout'            # :12
@@ -66,6 +67,8 @@ DATA_VARS_STD = {'T': 12.86922902730058, 'P': 113.14531431220384, 'PB': 9284.244
                  'QSNOW': 6.546815799049338e-07, 'QGRAUP': 0.0, 'U': 1.890336787350396,
                  'V': 2.3707455801620534, 'W': 0.041930900232612055,
                  'QCLOUD': 1.0485764700858156e-05}
+
+DEVICE_STATS = False    # True: per-file reductions run on the GPU (ops.field_stats)
 
 xr = None     # the xarray module, imported on first use (tests assign a stand-in)
 
@@ -277,7 +280,7 @@ def calculate_data_range(data_size):
         for data in DATA_VARS:
             if data not in true_vars:
                 continue
-            hi, lo = float(ds[data].max()), float(ds[data].min())
+            hi, lo = _fields.summary(ds[data], DEVICE_STATS)[:2]
             if data not in max_value or hi > max_value[data]:
                 max_value[data] = hi
             if data not in min_value or lo < min_value[data]:
@@ -299,9 +302,9 @@ def calculate_data_mean_std(data_size):
         for data in DATA_VARS:
             if data not in true_vars:
                 continue
-            size = ds[data].size
-            mean_value[data] = mean_value.get(data, 0) + float(ds[data].mean())
-            std_value[data] = std_value.get(data, 0) + (float(ds[data].std()) ** 2) * size
+            _, _, m, sd, size = _fields.summary(ds[data], DEVICE_STATS)
+            mean_value[data] = mean_value.get(data, 0) + m
+            std_value[data] = std_value.get(data, 0) + (sd ** 2) * size
             n += size
         ds.close()
     for data in DATA_VARS:
