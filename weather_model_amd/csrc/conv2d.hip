@@ -16,6 +16,7 @@
 // The weight-gradient reduction is wavefront-shuffle -> LDS -> float64 per-block partials in the
 // caller's workspace -> a fixed-order float64 finalize kernel (bitwise reproducible).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -176,6 +177,163 @@ __global__ __launch_bounds__(BLOCK) void conv_fwd_c1_kernel(
         fwd_batch<KH, KW, RB>(xq, yq, win, wr, bias, relu, h, hmin, H, W, OW);
     for (; s < wk.steps; ++s)
         fwd_batch<KH, KW, 1>(xq, yq, win, wr, bias, relu, h, hmin, H, W, OW);
+}
+
+// ------------------------------------------------------------------------------------------
+// Forward, flat-aligned variant (W % 4 == 0, rows up to ~4000 wide): what BASELINE config 3 runs.
+//
+// Measured on the 64 x 721 x 1440 grid: the strip kernel above runs (3,1) and (1,1) -- where
+// OW == W and every wave stores one 128-byte-aligned KiB -- in 106-109 us, but (3,3), (1,3),
+// (5,5), (2,2) in 125-133 us, whatever the load scheme, the output pitch or the tail handling;
+// with a padded output pitch AND 256-column wave spacing (3,3) drops to 112 us.  The cost is the
+// wave-level store that straddles 128-byte lines: rows of OW = W-KW+1 floats start at every
+// 8-byte phase.  So here the output leaves through LDS: one workgroup owns one contiguous range
+// of output rows = one contiguous range of the FLAT output; lanes drop their results into an LDS
+// ring at their flat position, and after every batch of rows the workgroup flushes the finished
+// part of the ring with 16-byte stores whose wave-level KiB chunks are aligned in flat space.
+// Loads: a lane loads only its own four columns (one aligned dwordx4 per row) and takes the KW-1
+// halo columns from lane+1 by shuffle; the last lane of a wave is a halo-only provider.
+template <int KW>
+struct WaveCols {
+    static constexpr int HALO = (KW - 1 + 3) / 4;          // halo lanes per wave (0 or 1)
+    static constexpr int CW = 4 * (64 - HALO);             // output columns per wave
+};
+
+struct FlatOut {
+    float *yb;           // y + (flat start of the range rounded down to a multiple of 4)
+    int prow;            // flat offset (from yb) of the next output row
+    int head, tail;      // offsets below head / from tail on are stored directly (ragged ends)
+    int flushed;         // everything in [head, flushed) has left the ring
+    int phase;           // (yb - y) mod 256: makes the flush chunks KiB-aligned in flat space
+    int mask;            // ring size - 1 (power of two)
+};
+
+template <int KH, int KW, int NB>
+__device__ __forceinline__ void load_rows_f(f32x4 (&rows)[NB], const float *__restrict__ p, int W)
+{
+#pragma unroll
+    for (int u = 0; u < NB; ++u) rows[u] = *reinterpret_cast<const f32x4 *>(p + (size_t)u * W);
+}
+
+// consume NB loaded rows: window shift, halo shuffle, outputs into the ring, then flush
+template <int KH, int KW, int NB>
+__device__ __forceinline__ void fwd_batch_f(const f32x4 (&rows)[NB], float *ring, FlatOut &fo,
+                                            float (&win)[KH][4 + KW - 1],
+                                            const float (&wr)[KH][KW], float bias, int relu,
+                                            int j0, int nst, int &h, int &hmin, int H, int OW)
+{
+    constexpr int EXT = 4 + KW - 1;
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+#pragma unroll
+        for (int kh = 0; kh < KH - 1; ++kh)
+#pragma unroll
+            for (int e = 0; e < EXT; ++e) win[kh][e] = win[kh + 1][e];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) win[KH - 1][e] = rows[u][e];
+#pragma unroll
+        for (int e = 4; e < EXT; ++e) win[KH - 1][e] = __shfl_down(rows[u][e - 4], 1, 64);
+        if (h >= hmin) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float acc = bias;
+#pragma unroll
+                for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < KW; ++kw) acc = fmaf(wr[kh][kw], win[kh][q + kw], acc);
+                acc = relu ? fmaxf(acc, 0.0f) : acc;
+                if (q < nst) {
+                    const int f = fo.prow + j0 + q;
+                    if (f < fo.head || f >= fo.tail) fo.yb[f] = acc;
+                    else ring[f & fo.mask] = acc;
+                }
+            }
+            fo.prow += OW;
+        }
+        const bool wrap = (h + 1 == H);
+        h = wrap ? 0 : h + 1;
+        hmin = wrap ? KH - 1 : hmin;
+    }
+    __syncthreads();
+    const int lim = min(fo.prow & ~3, fo.tail);
+    if (lim > fo.flushed) {
+        const int start = ((fo.flushed + fo.phase) & ~255) - fo.phase;
+        for (int f = start + 4 * (int)threadIdx.x; f < lim; f += 4 * (int)blockDim.x)
+            if (f >= fo.flushed) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(ring + (f & fo.mask));
+                __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(fo.yb + f));
+            }
+        fo.flushed = lim;
+    }
+    __syncthreads();
+}
+
+// one workgroup (wq_per_row waves) = one contiguous range of output rows
+template <int KH, int KW>
+__global__ __launch_bounds__(1024) void conv_fwd_c1f_kernel(
+    const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ b,
+    float *__restrict__ y, int H, int W, int OH, int OW, unsigned rows_base, unsigned rows_rem,
+    int relu, int ring_mask)
+{
+    extern __shared__ __attribute__((aligned(16))) float ring[];
+    constexpr int EXT = 4 + KW - 1;
+    const int lane = threadIdx.x & 63, wq = threadIdx.x >> 6;
+    const unsigned seg = blockIdx.x;
+    const unsigned r0 = seg * rows_base + min(seg, rows_rem);
+    const unsigned cnt = rows_base + (seg < rows_rem ? 1u : 0u);
+    const unsigned n0 = r0 / (unsigned)OH, i0 = r0 - n0 * (unsigned)OH;
+    const unsigned rl = r0 + cnt - 1;
+    const unsigned n1 = rl / (unsigned)OH, i1 = rl - n1 * (unsigned)OH;
+    const int steps = (int)((n1 - n0) * (unsigned)H + i1 + KH - i0);
+    const int j0 = wq * WaveCols<KW>::CW + 4 * lane;
+    const int nst = lane < 64 - WaveCols<KW>::HALO ? max(0, min(4, OW - j0)) : 0;
+    const float *__restrict__ xq = x + ((size_t)n0 * H + i0) * W + min(j0, W - 4);
+
+    const long long F0 = (long long)r0 * OW, Fb = F0 & ~3LL;
+    FlatOut fo;
+    fo.yb = y + Fb;
+    fo.prow = (int)(F0 - Fb);
+    fo.head = (fo.prow + 3) & ~3;
+    fo.tail = (int)((F0 + (long long)cnt * OW - Fb) & ~3LL);
+    if (fo.tail < fo.head) fo.tail = fo.head;
+    fo.flushed = fo.head;
+    fo.phase = (int)(Fb & 255);
+    fo.mask = ring_mask;
+
+    float wr[KH][KW];
+#pragma unroll
+    for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < KW; ++kw) wr[kh][kw] = w[kh * KW + kw];
+    const float bias = b ? b[0] : 0.0f;
+    int h = (int)i0, hmin = (int)i0 + KH - 1;
+    float win[KH][EXT];
+#pragma unroll
+    for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+        for (int e = 0; e < EXT; ++e) win[kh][e] = 0.0f;
+
+    // the loads of batch k+1 are in flight while batch k is consumed and flushed (the barriers of
+    // the flush would otherwise leave the memory pipe idle); the last batch re-reads its own rows
+    // instead of branching around the loads
+    const int nfull = steps / RB;
+    f32x4 cur[RB], nxt[RB];
+    if (nfull > 0) load_rows_f<KH, KW, RB>(cur, xq, W);
+    for (int bi = 0; bi < nfull; ++bi) {
+        const float *__restrict__ xn = xq + (bi + 1 < nfull ? (size_t)RB * W : (size_t)0);
+        load_rows_f<KH, KW, RB>(nxt, xn, W);
+        xq += (size_t)RB * W;
+        __builtin_amdgcn_sched_barrier(0);
+        fwd_batch_f<KH, KW, RB>(cur, ring, fo, win, wr, bias, relu, j0, nst, h, hmin, H, OW);
+#pragma unroll
+        for (int u = 0; u < RB; ++u) cur[u] = nxt[u];
+    }
+    for (int s = nfull * RB; s < steps; ++s) {
+        f32x4 one[1];
+        load_rows_f<KH, KW, 1>(one, xq, W);
+        xq += W;
+        fwd_batch_f<KH, KW, 1>(one, ring, fo, win, wr, bias, relu, j0, nst, h, hmin, H, OW);
+    }
 }
 
 template <int KH, int KW, int NB>
@@ -455,6 +613,44 @@ int stencil_plan(K kernel, int N, int OH, int OW, StencilPlan *p)
     return WM_OK;
 }
 
+// Launch shape of the flat-aligned forward: one workgroup of `waves` waves per row range, `segs`
+// ranges filling the chip once, an LDS ring of `ring` floats.  false: shape outside its limits.
+struct FlatPlan {
+    int waves, segs, ring;
+    unsigned rows_base, rows_rem;
+};
+
+template <typename K>
+bool flat_plan(K kernel, int N, int OH, int OW, int W, const void *x, const void *y,
+               int cols_per_wave, FlatPlan *p)
+{
+    if (W % 4 != 0 || (((uintptr_t)x | (uintptr_t)y) & 15) != 0) return false;
+    p->waves = (OW + cols_per_wave - 1) / cols_per_wave;
+    if (p->waves > 16) return false;
+    int ring = 1024;
+    while (ring < RB * OW + 8) ring *= 2;
+    if (ring > 16384) return false;                                  // 64 KB of LDS
+    p->ring = ring;
+    const int cus = wm_num_cus();
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, p->waves * 64,
+                                                     (size_t)ring * sizeof(float)) != hipSuccess)
+        return false;
+    if (occ < 1) return false;
+    if (occ * p->waves > 30) occ = 30 / p->waves > 0 ? 30 / p->waves : 1;   // stay fully resident
+    const long long total_rows = (long long)N * OH;
+    long long segs = (long long)cus * occ;
+    const long long max_segs = (total_rows + 7) / 8;
+    if (segs > max_segs) segs = max_segs;
+    if (const char *e = getenv("WM_EXP_ROWS")) segs = (total_rows + atoi(e) - 1) / atoi(e);
+    if (segs < 1) segs = 1;
+    p->segs = (int)segs;
+    p->rows_base = (unsigned)(total_rows / segs);
+    p->rows_rem = (unsigned)(total_rows % segs);
+    // 32-bit flat offsets inside a range
+    return ((long long)p->rows_base + 2) * OW < (1ll << 30);
+}
+
 bool stencil_shape(int Cin, int Cout, int kH, int kW, int OW, long long total_rows)
 {
     // 32-bit row arithmetic inside the kernels: N*H rows and strips*segs threads below 2^31
@@ -516,6 +712,19 @@ extern "C" int wm_conv2d_fwd_f32(const float *x, const float *w, const float *b,
     if (int rc = check_dims(N, Cin, H, W, Cout, kH, kW)) return rc;
     hipStream_t st = (hipStream_t)stream;
     const int OH = H - kH + 1, OW = W - kW + 1;
+    if (stencil_shape(Cin, Cout, kH, kW, OW, (long long)N * H)) {
+#define FWDF(KH_, KW_)                                                                          \
+    FlatPlan fp;                                                                                \
+    if (flat_plan(conv_fwd_c1f_kernel<KH_, KW_>, N, OH, OW, W, x, y, WaveCols<KW_>::CW, &fp)) { \
+        hipLaunchKernelGGL((conv_fwd_c1f_kernel<KH_, KW_>), dim3(fp.segs), dim3(fp.waves * 64), \
+                           (size_t)fp.ring * sizeof(float), st, x, w, b, y, H, W, OH, OW,       \
+                           fp.rows_base, fp.rows_rem, relu, fp.ring - 1);                       \
+        WM_LAUNCH_CHECK("conv_fwd_c1f_kernel");                                                 \
+        return WM_OK;                                                                           \
+    }
+        WM_STENCIL_DISPATCH(FWDF)
+#undef FWDF
+    }
     if (stencil_shape(Cin, Cout, kH, kW, OW, (long long)N * H)) {
 #define FWD(KH_, KW_)                                                                       \
     StencilPlan p;                                                                          \
