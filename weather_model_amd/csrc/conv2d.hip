@@ -16,7 +16,6 @@
 // The weight-gradient reduction is wavefront-shuffle -> LDS -> float64 per-block partials in the
 // caller's workspace -> a fixed-order float64 finalize kernel (bitwise reproducible).
 #include "common.h"
-#include <stdlib.h>
 
 namespace {
 
@@ -440,6 +439,126 @@ __global__ __launch_bounds__(BLOCK) void conv_bwd_wb_c1_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// Backward weight+bias, flat variant: the same decomposition as conv_fwd_c1f_kernel (a workgroup
+// spans the row, lanes load only their own four x columns and shuffle the halo in, short row
+// ranges taken in order), but persistent: a workgroup keeps its KH*KW+1 sums in registers over all
+// the ranges it takes (range b, b + grid, ...), so there is one float64 partial per workgroup.
+template <int KH, int KW, int NB>
+__device__ __forceinline__ void bwd_batch_f(const float *__restrict__ &xq,
+                                            const float *__restrict__ &gq,
+                                            float (&win)[KH][4 + KW - 1], float (&acc)[KH][KW],
+                                            float &accb, int nst, int gshift, int &h, int &hmin,
+                                            int H, int W, int OW)
+{
+    constexpr int EXT = 4 + KW - 1;
+    f32x4 rows[NB];
+    f4u gv[NB];
+    bool prod[NB];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        rows[u] = *reinterpret_cast<const f32x4 *>(xq + (size_t)u * W);
+        gv[u] = *reinterpret_cast<const f4u *>(gq);     // ignored on a non-producing step
+        prod[u] = h >= hmin;
+        gq += prod[u] ? OW : 0;
+        const bool wrap = (h + 1 == H);
+        h = wrap ? 0 : h + 1;
+        hmin = wrap ? KH - 1 : hmin;
+    }
+    xq += (size_t)NB * W;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+#pragma unroll
+        for (int kh = 0; kh < KH - 1; ++kh)
+#pragma unroll
+            for (int e = 0; e < EXT; ++e) win[kh][e] = win[kh + 1][e];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) win[KH - 1][e] = rows[u][e];
+#pragma unroll
+        for (int e = 4; e < EXT; ++e) win[KH - 1][e] = __shfl_down(rows[u][e - 4], 1, 64);
+        // the last strip of a row loads its gy four columns early (in bounds) and shifts
+        const float l0 = gv[u].x, l1 = gv[u].y, l2 = gv[u].z, l3 = gv[u].w;
+        float g[4];
+        g[0] = gshift == 0 ? l0 : (gshift == 1 ? l1 : (gshift == 2 ? l2 : l3));
+        g[1] = gshift == 0 ? l1 : (gshift == 1 ? l2 : l3);
+        g[2] = gshift == 0 ? l2 : l3;
+        g[3] = l3;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) g[q] = (prod[u] && q < nst) ? g[q] : 0.0f;
+#pragma unroll
+        for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < KW; ++kw)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    acc[kh][kw] = fmaf(g[q], win[kh][q + kw], acc[kh][kw]);
+        accb += (g[0] + g[1]) + (g[2] + g[3]);
+    }
+}
+
+template <int KH, int KW>
+__global__ __launch_bounds__(1024) void conv_bwd_wb_c1f_kernel(
+    const float *__restrict__ x, const float *__restrict__ gy, double *__restrict__ partial,
+    int H, int W, int OH, int OW, unsigned rows_base, unsigned rows_rem, unsigned segs)
+{
+    constexpr int EXT = 4 + KW - 1;
+    constexpr int NV = KH * KW + 1;
+    __shared__ float red[16][NV];
+    const int lane = threadIdx.x & 63, wq = threadIdx.x >> 6;
+    const int j0 = wq * WaveCols<KW>::CW + 4 * lane;
+    const int nst = lane < 64 - WaveCols<KW>::HALO ? max(0, min(4, OW - j0)) : 0;
+    const int jx = min(j0, W - 4), jg = min(j0, OW - 4);
+    const int gshift = min(j0 - jg, 3);
+
+    float acc[KH][KW];
+    float accb = 0.0f;
+#pragma unroll
+    for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < KW; ++kw) acc[kh][kw] = 0.0f;
+
+    for (unsigned seg = blockIdx.x; seg < segs; seg += gridDim.x) {
+        const unsigned r0 = seg * rows_base + min(seg, rows_rem);
+        const unsigned cnt = rows_base + (seg < rows_rem ? 1u : 0u);
+        const unsigned n0 = r0 / (unsigned)OH, i0 = r0 - n0 * (unsigned)OH;
+        const unsigned rl = r0 + cnt - 1;
+        const unsigned n1 = rl / (unsigned)OH, i1 = rl - n1 * (unsigned)OH;
+        const int steps = (int)((n1 - n0) * (unsigned)H + i1 + KH - i0);
+        const float *__restrict__ xq = x + ((size_t)n0 * H + i0) * W + jx;
+        const float *__restrict__ gq = gy + (size_t)r0 * OW + jg;
+        int h = (int)i0, hmin = (int)i0 + KH - 1;
+        float win[KH][EXT];
+#pragma unroll
+        for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+            for (int e = 0; e < EXT; ++e) win[kh][e] = 0.0f;
+        int s = 0;
+        for (; s + RB <= steps; s += RB)
+            bwd_batch_f<KH, KW, RB>(xq, gq, win, acc, accb, nst, gshift, h, hmin, H, W, OW);
+        for (; s < steps; ++s)
+            bwd_batch_f<KH, KW, 1>(xq, gq, win, acc, accb, nst, gshift, h, hmin, H, W, OW);
+    }
+    const int nwaves = blockDim.x >> 6;
+#pragma unroll
+    for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < KW; ++kw) {
+            const float s = wave_sum(acc[kh][kw]);
+            if (lane == 0) red[wq][kh * KW + kw] = s;
+        }
+    {
+        const float s = wave_sum(accb);
+        if (lane == 0) red[wq][NV - 1] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        double s = 0.0;
+        for (int v = 0; v < nwaves; ++v) s += (double)red[v][threadIdx.x];
+        partial[(size_t)blockIdx.x * NV + threadIdx.x] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // fixed-order float64 reduction of per-block partials: one wave per output entry.
 // partial is [nparts][nent]; out_w gets entries [0, nw), out_b gets [nw, nent).
 __global__ __launch_bounds__(64) void reduce_partials_kernel(const double *__restrict__ partial,
@@ -620,9 +739,15 @@ struct FlatPlan {
     unsigned rows_base, rows_rem;
 };
 
+// Row ranges are SHORT (2*RB - (kH-1) output rows, i.e. two full load batches) and one workgroup
+// takes one range: the dispatcher hands ranges out in order, so at any moment the resident
+// workgroups work on one compact window of x and of y that slides through memory.  Measured on
+// 64 x 721 x 1440, (3,3): ranges that fill the chip once (36 rows each, every workgroup streaming
+// its own far-apart 200 KB) 114 us; 6-row ranges in order 100 us; pure copy (1,1) 110 -> 90 us.
+// The halo rows two neighbouring ranges both read come out of L2 / Infinity Cache.
 template <typename K>
-bool flat_plan(K kernel, int N, int OH, int OW, int W, const void *x, const void *y,
-               int cols_per_wave, FlatPlan *p)
+bool flat_plan(K kernel, int N, int OH, int OW, int W, int kH, const void *x, const void *y,
+               int cols_per_wave, FlatPlan *p, long long target_segs = 0)
 {
     if (W % 4 != 0 || (((uintptr_t)x | (uintptr_t)y) & 15) != 0) return false;
     p->waves = (OW + cols_per_wave - 1) / cols_per_wave;
@@ -631,19 +756,16 @@ bool flat_plan(K kernel, int N, int OH, int OW, int W, const void *x, const void
     while (ring < RB * OW + 8) ring *= 2;
     if (ring > 16384) return false;                                  // 64 KB of LDS
     p->ring = ring;
-    const int cus = wm_num_cus();
-    int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, p->waves * 64,
-                                                     (size_t)ring * sizeof(float)) != hipSuccess)
-        return false;
-    if (occ < 1) return false;
-    if (occ * p->waves > 30) occ = 30 / p->waves > 0 ? 30 / p->waves : 1;   // stay fully resident
+    (void)kernel;
     const long long total_rows = (long long)N * OH;
-    long long segs = (long long)cus * occ;
-    const long long max_segs = (total_rows + 7) / 8;
-    if (segs > max_segs) segs = max_segs;
-    if (const char *e = getenv("WM_EXP_ROWS")) segs = (total_rows + atoi(e) - 1) / atoi(e);
+    int rows = 2 * RB - (kH - 1);
+    if (rows < RB) rows = RB;
+    long long segs = (total_rows + rows - 1) / rows;
+    // target_segs > 0 (backward, reads only: long ranges cost nothing and halve the halo): one
+    // range per workgroup, as even as possible
+    if (target_segs > 0 && target_segs < segs) segs = target_segs;
     if (segs < 1) segs = 1;
+    if (segs > 0x7fffffffLL) return false;
     p->segs = (int)segs;
     p->rows_base = (unsigned)(total_rows / segs);
     p->rows_rem = (unsigned)(total_rows % segs);
@@ -715,7 +837,9 @@ extern "C" int wm_conv2d_fwd_f32(const float *x, const float *w, const float *b,
     if (stencil_shape(Cin, Cout, kH, kW, OW, (long long)N * H)) {
 #define FWDF(KH_, KW_)                                                                          \
     FlatPlan fp;                                                                                \
-    if (flat_plan(conv_fwd_c1f_kernel<KH_, KW_>, N, OH, OW, W, x, y, WaveCols<KW_>::CW, &fp)) { \
+    if (KH_ * KW_ <= 9 &&                                                                       \
+        flat_plan(conv_fwd_c1f_kernel<KH_, KW_>, N, OH, OW, W, kH, x, y, WaveCols<KW_>::CW,     \
+                  &fp)) {                                                                       \
         hipLaunchKernelGGL((conv_fwd_c1f_kernel<KH_, KW_>), dim3(fp.segs), dim3(fp.waves * 64), \
                            (size_t)fp.ring * sizeof(float), st, x, w, b, y, H, W, OH, OW,       \
                            fp.rows_base, fp.rows_rem, relu, fp.ring - 1);                       \
@@ -790,7 +914,34 @@ extern "C" int wm_conv2d_bwd_wb_f32(const float *x, const float *gy, float *gw, 
     const int nw = Cout * Cin * kH * kW, nent = nw + Cout;
     double *partial = (double *)workspace;
     int nparts = 0;
+    bool flat_done = false;
     if (stencil_shape(Cin, Cout, kH, kW, OW, (long long)N * H)) {
+#define BWDF(KH_, KW_)                                                                          \
+    FlatPlan fp;                                                                                \
+    const int waves_ = (OW + WaveCols<KW_>::CW - 1) / WaveCols<KW_>::CW;                        \
+    int occ = 0;                                                                                \
+    if (KH_ * KW_ <= 9 && waves_ <= 16) {                                                       \
+        WM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(                                    \
+            &occ, conv_bwd_wb_c1f_kernel<KH_, KW_>, waves_ * 64, 0));                           \
+        if (occ * waves_ > 30) occ = 30 / waves_;                                               \
+        if (occ > 6) occ = 6;                                                                   \
+        if (occ < 1) occ = 1;                                                                   \
+    }                                                                                           \
+    if (occ > 0 &&                                                                              \
+        flat_plan(conv_bwd_wb_c1f_kernel<KH_, KW_>, N, OH, OW, W, kH, x, gy,                    \
+                  WaveCols<KW_>::CW, &fp, (long long)wm_num_cus() * occ)) {                     \
+        hipLaunchKernelGGL((conv_bwd_wb_c1f_kernel<KH_, KW_>), dim3((unsigned)fp.segs),         \
+                           dim3(fp.waves * 64), 0, st, x, gy, partial, H, W, OH, OW,            \
+                           fp.rows_base, fp.rows_rem, (unsigned)fp.segs);                       \
+        WM_LAUNCH_CHECK("conv_bwd_wb_c1f_kernel");                                              \
+        nparts = fp.segs;                                                                       \
+        flat_done = true;                                                                       \
+    }
+        WM_STENCIL_DISPATCH(BWDF)
+#undef BWDF
+    }
+    if (flat_done) {
+    } else if (stencil_shape(Cin, Cout, kH, kW, OW, (long long)N * H)) {
 #define BWD(KH_, KW_)                                                                         \
     StencilPlan p;                                                                            \
     if (int rc = stencil_plan(conv_bwd_wb_c1_kernel<KH_, KW_>, N, OH, OW, &p)) return rc;     \
