@@ -55,6 +55,12 @@ def dist_setup(ngpus):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
+        # WM_BENCH_REHEARSAL=1: every rank on GPU 0 over gloo -- exercises the N > 1 code path on
+        # a one-GPU box (numbers from such a run mean nothing)
+        if os.environ.get("WM_BENCH_REHEARSAL"):
+            torch.cuda.set_device(0)
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+            return rank, world, 0
         torch.cuda.set_device(local)
         dist.init_process_group(backend="nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local))
@@ -75,7 +81,8 @@ def max_over_ranks(value, world):
     if world == 1:
         return value
     import torch.distributed as dist
-    t = torch.tensor([value], device="cuda", dtype=torch.float64)
+    t = torch.tensor([value], dtype=torch.float64,
+                     device="cpu" if dist.get_backend() == "gloo" else "cuda")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -293,8 +300,13 @@ def run_model(steps, warmup, rank, world, cpu_base, B=721 * 1440):
     evs = []
     state = {"step": 0}
 
+    trace = bool(os.environ.get("WM_BENCH_TRACE"))
+
     def step(i, timed):
         st = torch.cuda.current_stream().cuda_stream
+        if trace:
+            torch.cuda.synchronize()
+            print(f"[rank {rank}] model step {i} start", file=sys.stderr, flush=True)
         if timed:
             e = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             e[0].record()
@@ -304,8 +316,14 @@ def run_model(steps, warmup, rank, world, cpu_base, B=721 * 1440):
         if timed:
             e[1].record()
             evs.append(e)
+        if trace:
+            torch.cuda.synchronize()
+            print(f"[rank {rank}] model step {i} kernel done", file=sys.stderr, flush=True)
         if world > 1:
             dp.reduce_grads_(grads)          # 82 KB flat gradient buffer, one collective
+        if trace:
+            torch.cuda.synchronize()
+            print(f"[rank {rank}] model step {i} reduced", file=sys.stderr, flush=True)
         state["step"] += 1
         _lib.check(L.wm_adam_step_f32(params.data_ptr(), grads.data_ptr(), m.data_ptr(),
                                       v.data_ptr(), params.numel(), state["step"], 1e-3, 0.9,

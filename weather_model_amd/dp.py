@@ -34,7 +34,14 @@ def allreduce_sum_(t: torch.Tensor) -> torch.Tensor:
     if world() > 1:
         if not t.is_contiguous():
             raise ValueError("all-reduce needs one contiguous buffer (do not fragment it)")
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        if t.is_cuda and dist.get_backend() == "gloo":
+            # rehearsals of the N > 1 path on a one-GPU box: stage through the host (gloo's own
+            # device path was seen to dead-lock with two ranks sharing one GPU)
+            host = t.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            t.copy_(host)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
 
 
