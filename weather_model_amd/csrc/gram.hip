@@ -473,7 +473,11 @@ __global__ __launch_bounds__(BLOCK) void gram_tile_finalize_kernel(
 }
 
 // ---------------------------------------------------------------------------- solve
-// One workgroup.  A (F x F) and B (F x P) live in LDS when they fit, else in the workspace.
+// One workgroup.  A, L (F x F) and B, Z (F x P) live in LDS when they fit, else in the workspace.
+// Every elimination step is ONE barrier-separated phase: the scaled column goes to a separate
+// array (L, Z, beta) so the trailing update can read the unscaled one in the same phase, and the
+// pivot reciprocal is recomputed by every thread instead of being broadcast through memory
+// (a 17 x 17 system: 3 F phases instead of 7 F; 28 -> ~10 us).
 template <bool USE_LDS>
 __global__ __launch_bounds__(BLOCK) void normal_solve_kernel(const double *__restrict__ acc, int F,
                                                              int P, int fit_intercept, double ridge,
@@ -481,84 +485,110 @@ __global__ __launch_bounds__(BLOCK) void normal_solve_kernel(const double *__res
                                                              int *__restrict__ status,
                                                              double *__restrict__ ws)
 {
-    // all LDS in the dynamic region (16-byte aligned base): 2 doubles of flags, then A and B
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    volatile int &bad = *reinterpret_cast<volatile int *>(smem);
     const int D = F + 1 + P;
-    double *A = USE_LDS ? smem + 2 : ws;
-    double *B = A + (size_t)F * F;
+    double *A = USE_LDS ? smem : ws;
+    double *L = A + (size_t)F * F;
+    double *B = L + (size_t)F * F;
+    double *Z = B + (size_t)F * P;
+    double *S = Z + (size_t)F * P;      // column sums of X   [F]
+    double *T = S + F;                  // column sums of Y   [P]
+    double *R = T + P;                  // 1 / L[k][k]        [F]
     const int tid = threadIdx.x;
-    const int NT = blockDim.x;   // 64 (one wave: barriers are free) for small systems, else 256
+    const int NT = blockDim.x;   // 64 (one wave) for small systems, else 256
+    // every global read of this kernel is issued in two parallel sweeps (a dependent chain of
+    // L2-miss latencies was most of the 28 us the first version took for a 17 x 17 system)
+    for (int i = tid; i < F; i += NT) S[i] = acc[(size_t)i * D + F];
+    for (int p = tid; p < P; p += NT) T[p] = acc[(size_t)F * D + F + 1 + p];
     const double n = acc[(size_t)F * D + F];
     const double inv_n = (fit_intercept && n > 0.0) ? 1.0 / n : 0.0;
-    if (tid == 0) bad = (fit_intercept && !(n > 0.0)) ? 1 : 0;
+    bool bad = fit_intercept && !(n > 0.0);          // uniform: every thread sees the same values
+#pragma unroll 4
+    for (int e = tid; e < F * F; e += NT) A[e] = acc[(size_t)(e / F) * D + e % F];
+#pragma unroll 4
+    for (int e = tid; e < F * P; e += NT) B[e] = acc[(size_t)(e / P) * D + F + 1 + e % P];
+    __syncthreads();
     for (int e = tid; e < F * F; e += NT) {
         const int i = e / F, j = e % F;
-        double v = acc[(size_t)i * D + j] - acc[(size_t)i * D + F] * acc[(size_t)j * D + F] * inv_n;
+        double v = A[e] - S[i] * S[j] * inv_n;
         if (i == j) v += ridge;
         A[e] = v;
     }
-    for (int e = tid; e < F * P; e += NT) {
-        const int i = e / P, p = e % P;
-        B[e] = acc[(size_t)i * D + F + 1 + p] -
-               acc[(size_t)i * D + F] * acc[(size_t)F * D + F + 1 + p] * inv_n;
-    }
+    for (int e = tid; e < F * P; e += NT) B[e] -= S[e / P] * T[e % P] * inv_n;
     __syncthreads();
-    // right-looking Cholesky, lower triangle in place
-    for (int k = 0; k < F; ++k) {
-        if (tid == 0) {
-            const double dk = A[(size_t)k * F + k];
-            if (!(dk > 0.0)) bad = 1;
-            A[(size_t)k * F + k] = sqrt(dk > 0.0 ? dk : 1.0);
+    // small systems (one wave): each lane's lower-triangle elements are fixed for the whole
+    // factorisation, so the (i, j) decode -- two integer divisions per element and step in the
+    // generic loop below, most of its instructions -- is done once
+    constexpr int SMALL_MAX = 24, SMALL_ELEMS = SMALL_MAX * SMALL_MAX / 64;
+    const bool small = USE_LDS && NT == 64 && F <= SMALL_MAX;
+    int ei[SMALL_ELEMS], ej[SMALL_ELEMS];
+    if (small) {
+#pragma unroll
+        for (int r = 0; r < SMALL_ELEMS; ++r) {
+            const int e = tid + 64 * r;
+            ei[r] = e / F;
+            ej[r] = e % F;
+            if (e >= F * F || ej[r] > ei[r]) ei[r] = -1;      // not a lower-triangle element
         }
-        __syncthreads();
-        if (bad) break;
+    }
+    // right-looking Cholesky: L[i][k] = A[i][k] / sqrt(d), A[i][j] -= A[i][k] A[j][k] / d
+    for (int k = 0; k < F && !bad; ++k) {
         const double dk = A[(size_t)k * F + k];
-        for (int i = k + 1 + tid; i < F; i += NT) A[(size_t)i * F + k] /= dk;
-        __syncthreads();
-        const int m = F - k - 1;
-        for (int e = tid; e < m * m; e += NT) {
-            const int i = k + 1 + e / m, j = k + 1 + e % m;
-            if (j <= i) A[(size_t)i * F + j] -= A[(size_t)i * F + k] * A[(size_t)j * F + k];
+        if (!(dk > 0.0)) { bad = true; break; }
+        // one reciprocal square root per step and no division anywhere: a float64 divide or
+        // square root is a long dependent chain, and this kernel is nothing but such chains
+        const double rs = rsqrt(dk), inv = rs * rs;
+        if (tid == 0) R[k] = rs;
+        for (int i = k + tid; i < F; i += NT) L[(size_t)i * F + k] = A[(size_t)i * F + k] * rs;
+        if (small) {
+#pragma unroll
+            for (int r = 0; r < SMALL_ELEMS; ++r)
+                if (ej[r] > k && ei[r] >= 0)              // j > k (and i >= j > k)
+                    A[ei[r] * F + ej[r]] -= A[ei[r] * F + k] * A[ej[r] * F + k] * inv;
+        } else {
+            const int m = F - k - 1;
+            for (int e = tid; e < m * m; e += NT) {
+                const int i = k + 1 + e / m, j = k + 1 + e % m;
+                if (j <= i)
+                    A[(size_t)i * F + j] -= A[(size_t)i * F + k] * A[(size_t)j * F + k] * inv;
+            }
         }
         __syncthreads();
     }
     if (!bad) {
-        // forward substitution L z = B (column oriented), then back substitution L' beta = z
+        // forward substitution L z = B (column oriented): Z[k] = B[k] / L[k][k]
         for (int k = 0; k < F; ++k) {
-            const double dk = A[(size_t)k * F + k];
-            for (int p = tid; p < P; p += NT) B[(size_t)k * P + p] /= dk;
-            __syncthreads();
+            const double rk = R[k];
+            for (int p = tid; p < P; p += NT) Z[(size_t)k * P + p] = B[(size_t)k * P + p] * rk;
             const int m = F - k - 1;
             for (int e = tid; e < m * P; e += NT) {
                 const int i = k + 1 + e / P, p = e % P;
-                B[(size_t)i * P + p] -= A[(size_t)i * F + k] * B[(size_t)k * P + p];
+                B[(size_t)i * P + p] -= L[(size_t)i * F + k] * (B[(size_t)k * P + p] * rk);
             }
             __syncthreads();
         }
+        // back substitution L' beta = z: B[k] = Z[k] / L[k][k] is the answer row
         for (int k = F - 1; k >= 0; --k) {
-            const double dk = A[(size_t)k * F + k];
-            for (int p = tid; p < P; p += NT) B[(size_t)k * P + p] /= dk;
-            __syncthreads();
+            const double rk = R[k];
+            for (int p = tid; p < P; p += NT) B[(size_t)k * P + p] = Z[(size_t)k * P + p] * rk;
             for (int e = tid; e < k * P; e += NT) {
                 const int i = e / P, p = e % P;
-                B[(size_t)i * P + p] -= A[(size_t)k * F + i] * B[(size_t)k * P + p];
+                Z[(size_t)i * P + p] -= L[(size_t)k * F + i] * (Z[(size_t)k * P + p] * rk);
             }
             __syncthreads();
         }
     }
     const double qnan = __longlong_as_double(0x7ff8000000000000LL);
     for (int e = tid; e < F * P; e += NT) beta[e] = bad ? qnan : B[e];
-    __syncthreads();
     for (int p = tid; p < P; p += NT) {
         double icpt = 0.0;
         if (fit_intercept && !bad) {
-            icpt = acc[(size_t)F * D + F + 1 + p] * inv_n;
-            for (int i = 0; i < F; ++i) icpt -= acc[(size_t)i * D + F] * inv_n * B[(size_t)i * P + p];
+            icpt = T[p] * inv_n;
+            for (int i = 0; i < F; ++i) icpt -= S[i] * inv_n * B[(size_t)i * P + p];
         }
         beta[(size_t)F * P + p] = bad ? qnan : icpt;
     }
-    if (tid == 0 && status) *status = bad;
+    if (tid == 0 && status) *status = bad ? 1 : 0;
 }
 
 __global__ __launch_bounds__(BLOCK) void linear_predict_kernel(const float *__restrict__ X,
@@ -617,7 +647,7 @@ void tile_plan(long long n, int F, int P, int *DT, int *pairs, int *slices)
     *slices = (int)s;
 }
 
-constexpr size_t SOLVE_LDS_LIMIT = 48 * 1024;
+constexpr size_t SOLVE_LDS_LIMIT = 128 * 1024;   // one workgroup on the CU: most of its 160 KB
 
 }  // namespace
 
@@ -685,7 +715,7 @@ extern "C" int wm_gram_f32(const float *X, const float *Y, int64_t n, int F, int
 extern "C" size_t wm_normal_solve_workspace_bytes(int F, int P)
 {
     if (F <= 0 || P <= 0) return 0;
-    const size_t b = ((size_t)F * F + (size_t)F * P) * sizeof(double);
+    const size_t b = (2 * ((size_t)F * F + (size_t)F * P) + 2 * (size_t)F + P) * sizeof(double);
     return b <= SOLVE_LDS_LIMIT ? 0 : wm_align_up(b, 256);
 }
 
@@ -697,16 +727,23 @@ extern "C" int wm_normal_solve_f64(const double *acc, int F, int P, int fit_inte
     WM_REQUIRE(F > 0 && P > 0, WM_ERR_INVALID, "wm_normal_solve_f64: bad sizes F=%d P=%d", F, P);
     WM_REQUIRE(ridge >= 0.0, WM_ERR_INVALID, "wm_normal_solve_f64: negative ridge");
     hipStream_t st = (hipStream_t)stream;
-    const size_t bytes = ((size_t)F * F + (size_t)F * P) * sizeof(double);
+    const size_t bytes = (2 * ((size_t)F * F + (size_t)F * P) + 2 * (size_t)F + P) * sizeof(double);
     if (bytes <= SOLVE_LDS_LIMIT) {
-        hipLaunchKernelGGL(normal_solve_kernel<true>, dim3(1), dim3(F <= 24 ? 64 : BLOCK), bytes + 16, st, acc, F, P,
+        static bool attr_set = false;
+        if (!attr_set) {
+            WM_HIP(hipFuncSetAttribute((const void *)normal_solve_kernel<true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)SOLVE_LDS_LIMIT));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(normal_solve_kernel<true>, dim3(1), dim3(F <= 24 ? 64 : BLOCK), bytes, st, acc, F, P,
                            fit_intercept, ridge, beta, status, (double *)nullptr);
     } else {
         const size_t need = wm_normal_solve_workspace_bytes(F, P);
         WM_REQUIRE(workspace && workspace_bytes >= need, WM_ERR_WORKSPACE,
                    "wm_normal_solve_f64: workspace of %zu bytes needed, %zu given", need,
                    workspace_bytes);
-        hipLaunchKernelGGL(normal_solve_kernel<false>, dim3(1), dim3(BLOCK), 16, st, acc, F, P,
+        hipLaunchKernelGGL(normal_solve_kernel<false>, dim3(1), dim3(BLOCK), 0, st, acc, F, P,
                            fit_intercept, ridge, beta, status, (double *)workspace);
     }
     WM_LAUNCH_CHECK("normal_solve_kernel");
