@@ -247,9 +247,9 @@ def run_conv(steps, warmup, rank, world, cpu_base, N=64, H=721, W=1440):
         "roofline": {"bound": "hbm",
                      "achieved": (fwd_bytes + bwd_bytes) / ((fwd_ms + bwd_ms) * 1e-3) / 1e9,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "traffic": pmc_traffic(["conv_fwd_c1_kernel<3, 3>", "conv_bwd_wb_c1_kernel<3, 3>"],
+                     "traffic": pmc_traffic(["conv_fwd_c1f_kernel<3, 3>", "conv_bwd_wb_c1f_kernel<3, 3>"],
                                             (N, H, W) == (64, 721, 1440)),
-                     "kernel": "conv_fwd_c1_kernel<3,3> + conv_bwd_wb_c1_kernel<3,3>",
+                     "kernel": "conv_fwd_c1f_kernel<3,3> + conv_bwd_wb_c1f_kernel<3,3>",
                      "fwd_GBs": fwd_bytes / (fwd_ms * 1e-3) / 1e9,
                      "bwd_wb_GBs": bwd_bytes / (bwd_ms * 1e-3) / 1e9,
                      "algorithmic_bytes_per_point": 16},

@@ -535,7 +535,25 @@ __device__ __forceinline__ void param_src(int p, int &id, int &el)
     }
 }
 
-__global__ __launch_bounds__(256) void model_grad_finalize_kernel(const float *__restrict__ gtiles,
+constexpr int GSPLIT = 4;      // workgroup ranges summed separately, then combined in order
+
+// stage 1: tile-space sums over the workgroups, coalesced (thread = one tile element).
+// tsum: [GSPLIT][NTILES][256] float64.
+__global__ __launch_bounds__(256) void model_tile_reduce_kernel(const float *__restrict__ gtiles,
+                                                                int nblocks,
+                                                                double *__restrict__ tsum)
+{
+    const int id = blockIdx.x, part = blockIdx.y, el = threadIdx.x;
+    const int b0 = (int)((long long)nblocks * part / GSPLIT);
+    const int b1 = (int)((long long)nblocks * (part + 1) / GSPLIT);
+    double s = 0.0;
+#pragma unroll 8
+    for (int b = b0; b < b1; ++b) s += (double)gtiles[((size_t)b * NTILES + id) * 256 + el];
+    tsum[((size_t)part * NTILES + id) * 256 + el] = s;
+}
+
+// stage 2: tile space -> PyTorch parameter layout, partial sums combined in a fixed order
+__global__ __launch_bounds__(256) void model_grad_finalize_kernel(const double *__restrict__ tsum,
                                                                   const float *__restrict__ loss_part,
                                                                   int nblocks, float *__restrict__ grads,
                                                                   float *__restrict__ loss, float loss_scale)
@@ -545,7 +563,8 @@ __global__ __launch_bounds__(256) void model_grad_finalize_kernel(const float *_
         int id, el;
         param_src(p, id, el);
         double s = 0.0;
-        for (int b = 0; b < nblocks; ++b) s += (double)gtiles[((size_t)b * NTILES + id) * 256 + el];
+#pragma unroll
+        for (int part = 0; part < GSPLIT; ++part) s += tsum[((size_t)part * NTILES + id) * 256 + el];
         grads[p] = (float)s;
     }
     if (p == 0 && loss && loss_part) {
@@ -606,7 +625,8 @@ extern "C" size_t wm_model_workspace_bytes(int64_t B)
 {
     if (B <= 0 || wm_num_cus() <= 0) return 0;
     const size_t blocks = (size_t)wm_num_cus();
-    return wm_align_up(blocks * NTILES * 256 * sizeof(float) + blocks * sizeof(float) + 256, 256);
+    return wm_align_up(blocks * NTILES * 256 * sizeof(float) + blocks * sizeof(float) + 256, 256) +
+           (size_t)GSPLIT * NTILES * 256 * sizeof(double);
 }
 
 extern "C" int wm_model_fwd_f32(const float *params, const float *x, float *out, int64_t B,
@@ -643,8 +663,13 @@ extern "C" int wm_model_train_f32(const float *params, const float *x, const flo
     if (y) rc = model_launch<1>(params, x, y, nullptr, out, gtiles, loss_part, B, dscale, grid, st);
     else   rc = model_launch<2>(params, x, nullptr, dout, out, gtiles, loss_part, B, dscale, grid, st);
     if (rc) return rc;
+    double *tsum = (double *)((char *)workspace + need -
+                              (size_t)GSPLIT * NTILES * 256 * sizeof(double));
+    hipLaunchKernelGGL(model_tile_reduce_kernel, dim3(NTILES, GSPLIT), dim3(256), 0, st, gtiles, grid,
+                       tsum);
+    WM_LAUNCH_CHECK("model_tile_reduce_kernel");
     hipLaunchKernelGGL(model_grad_finalize_kernel, dim3((NPARAM + 255) / 256), dim3(256), 0, st,
-                       gtiles, y ? loss_part : (const float *)nullptr, grid, grads,
+                       tsum, y ? loss_part : (const float *)nullptr, grid, grads,
                        y ? loss : (float *)nullptr, dscale);
     WM_LAUNCH_CHECK("model_grad_finalize_kernel");
     return WM_OK;
