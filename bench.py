@@ -368,12 +368,86 @@ def run_model(steps, warmup, rank, world, cpu_base, B=721 * 1440):
     return res
 
 
+# ------------------------------------------------------------------------------ field kernels
+def run_fields(steps, warmup, rank, world, cpu_base):
+    """one-pass statistics, normalise and the sample gather, each on a
+    64 x 721 x 1440 field (266 MB, 3 rotating copies) / one 721 x 1440 slice of samples."""
+    from weather_model_amd import ops
+    n = 64 * 721 * 1440
+    nset = 3
+    fields = [ops.synth_uniform((n,), seed=70 + k, lo=-50.0, hi=1300.0, offset=rank * n)
+              for k in range(nset)]
+    outs = [torch.empty_like(f) for f in fields]
+    T, Z, Y, X, V = 9, 1, 721, 1440, 6
+    vol = ops.synth_uniform((T, Z, Y, X, V), seed=80, offset=rank * T * Z * Y * X * V)
+    B = Y * X
+    stat = torch.zeros((5,), device="cuda", dtype=torch.float64)
+
+    def timed(fn):
+        ev = []
+
+        def step(i, t):
+            if t:
+                e = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                e[0].record()
+            fn(i)
+            if t:
+                e[1].record()
+                ev.append(e)
+        total = timed_steps(step, steps, warmup, world)
+        return total / steps, float(np.mean([a.elapsed_time(c) for a, c in ev])) * 1e-3
+
+    t_stat, k_stat = timed(lambda i: ops.field_stats(fields[i % nset], stat))
+    t_norm, k_norm = timed(lambda i: ops.affine_scale(fields[i % nset], -50.0, 1350.0,
+                                                      out=outs[i % nset]))
+    t_gath, k_gath = timed(lambda i: ops.gather_triplets(vol, (T - 6, Z, Y, X), first=0, count=B))
+    res = {
+        "unit": "elements/s",
+        "config": {"workload": "field kernels: stats + normalise over 64x721x1440 fp32, triplet "
+                               "gather of one 721x1440 slice (6 variables)"},
+        "stats": {"value": n * world / t_stat, "ms": t_stat * 1e3,
+                  "roofline": {"bound": "hbm", "achieved": 4 * n / k_stat / 1e9,
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": 4 * n / k_stat / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                               "kernel": "field_stats_kernel", "algorithmic_bytes_per_element": 4}},
+        "normalise": {"value": n * world / t_norm, "ms": t_norm * 1e3,
+                      "roofline": {"bound": "hbm", "achieved": 8 * n / k_norm / 1e9,
+                                   "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": 8 * n / k_norm / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                   "kernel": "affine_scale_kernel",
+                                   "algorithmic_bytes_per_element": 8}},
+        "gather": {"value": B * world / t_gath, "unit": "samples/s", "ms": t_gath * 1e3,
+                   "roofline": {"bound": "hbm", "achieved": 144 * B / k_gath / 1e9,
+                                "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": 144 * B / k_gath / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                "kernel": "gather_triplets_kernel",
+                                "algorithmic_bytes_per_sample": 144}},
+    }
+    res["value"] = res["stats"]["value"]
+    res["ms_per_step"] = (t_stat + t_norm + t_gath) * 1e3
+    if cpu_base and rank == 0 and world == 1:
+        from oracle import cpu as ocpu
+        m = 8_000_000
+        xs = fields[0][:m].cpu().numpy()
+        best = 1e30
+        t_end = time.perf_counter() + 5.0
+        while time.perf_counter() < t_end:
+            t0 = time.perf_counter()
+            ocpu.field_stats(xs)
+            ocpu.affine_scale(xs, -50.0, 1350.0)
+            best = min(best, time.perf_counter() - t0)
+        res["cpu_baseline"] = {"value": m / best, "unit": "elements/s (stats + normalise)",
+                               "cores": 1, "kind": "port",
+                               "sample": f"{m} elements, oracle/cpu.py numpy restatement"}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="all", choices=["all", "gram16", "conv3x3", "gram64", "model32"])
+    ap.add_argument("--workload", default="all", choices=["all", "gram16", "conv3x3", "gram64", "model32", "fields"])
     ap.add_argument("--rows", type=int, default=100_000_000, help="rows per GPU (gram workloads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -424,6 +498,17 @@ def main():
                 out["cpu_baseline"] = mres["cpu_baseline"]
         else:
             out.setdefault("also", {})["model32"] = mres
+    if args.workload in ("all", "fields"):
+        fres = run_fields(args.steps, args.warmup, rank, world, cpu_base)
+        if args.workload == "fields":
+            out.update({"metric": "elements/s field statistics", "unit": "elements/s",
+                        "value": fres["value"], "ms_per_step": fres["ms_per_step"],
+                        "roofline": fres["stats"]["roofline"], "config": fres["config"],
+                        "normalise": fres["normalise"], "gather": fres["gather"]})
+            if "cpu_baseline" in fres:
+                out["cpu_baseline"] = fres["cpu_baseline"]
+        else:
+            out.setdefault("also", {})["fields"] = fres
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

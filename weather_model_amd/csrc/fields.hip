@@ -17,15 +17,15 @@ constexpr int NSTAT = 5;      // min, max, sum, sumsq, count
 __device__ __forceinline__ void stat_add(float v, float &mn, float &mx, double &s, double &ss,
                                          double &cnt)
 {
-    // NaNs are skipped, as xarray's reductions do by default (skipna for float data)
-    if (v == v) {
-        mn = fminf(mn, v);
-        mx = fmaxf(mx, v);
-        const double d = (double)v;
-        s += d;
-        ss = fma(d, d, ss);
-        cnt += 1.0;
-    }
+    // NaNs are skipped, as xarray's reductions do by default (skipna for float data); branch-free:
+    // fminf/fmaxf return the other operand for a NaN, the sums take a zero
+    const bool ok = v == v;
+    mn = fminf(mn, v);
+    mx = fmaxf(mx, v);
+    const double d = ok ? (double)v : 0.0;
+    s += d;
+    ss = fma(d, d, ss);
+    cnt += ok ? 1.0 : 0.0;
 }
 
 // partial: [gridDim.x][NSTAT] float64
@@ -85,24 +85,36 @@ __global__ __launch_bounds__(BLOCK) void field_stats_kernel(const float *__restr
     }
 }
 
-// fixed-order combine of the block partials; merges into out when accumulate != 0
+// fixed-order combine of the block partials (lane l takes parts l, l+64, ... in order, then a
+// shuffle tree: the same association every run); merges into out when accumulate != 0
 __global__ __launch_bounds__(64) void field_stats_finalize_kernel(const double *__restrict__ partial,
                                                                   int nparts,
                                                                   double *__restrict__ out,
                                                                   int accumulate)
 {
-    if (threadIdx.x != 0) return;
     double r[NSTAT] = {__builtin_inf(), -__builtin_inf(), 0.0, 0.0, 0.0};
-    if (accumulate) {
-#pragma unroll
-        for (int k = 0; k < NSTAT; ++k) r[k] = out[k];
-    }
-    for (int p = 0; p < nparts; ++p) {
+    for (int p = threadIdx.x; p < nparts; p += 64) {
         r[0] = fmin(r[0], partial[(size_t)p * NSTAT + 0]);
         r[1] = fmax(r[1], partial[(size_t)p * NSTAT + 1]);
         r[2] += partial[(size_t)p * NSTAT + 2];
         r[3] += partial[(size_t)p * NSTAT + 3];
         r[4] += partial[(size_t)p * NSTAT + 4];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        r[0] = fmin(r[0], __shfl_xor(r[0], o, 64));
+        r[1] = fmax(r[1], __shfl_xor(r[1], o, 64));
+        r[2] += __shfl_xor(r[2], o, 64);
+        r[3] += __shfl_xor(r[3], o, 64);
+        r[4] += __shfl_xor(r[4], o, 64);
+    }
+    if (threadIdx.x != 0) return;
+    if (accumulate) {
+        r[0] = fmin(r[0], out[0]);
+        r[1] = fmax(r[1], out[1]);
+        r[2] += out[2];
+        r[3] += out[3];
+        r[4] += out[4];
     }
 #pragma unroll
     for (int k = 0; k < NSTAT; ++k) out[k] = r[k];
