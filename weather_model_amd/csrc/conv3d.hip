@@ -21,6 +21,7 @@ constexpr int BLOCK = 256;
 constexpr int WAVES = BLOCK / 64;
 constexpr int KCHUNK = 4096;      // table entries resident in LDS at a time
 constexpr int NCHUNK = 1024;      // outputs per weight-gradient split
+constexpr int UNR = 4;            // MFMA steps whose operand loads are issued together
 
 struct Dims3 {
     int B, Cin, D, H, W, Cout, kD, kH, kW, OD, OH, OW;
@@ -43,8 +44,24 @@ __device__ __forceinline__ int tap_offset(const Dims3 &d, int k)
     return ((c * d.D + kd) * d.H + kh) * d.W + kw;
 }
 
+// Combine the WAVES per-wave partial accumulators of one column tile (fixed order) and hand every
+// thread its share of the OT*256 outputs: element idx = t*256 + lane*4 + r.
+template <int OT>
+__device__ __forceinline__ void reduce_tiles(float *part, const f32x4 (&acc)[OT], int wave, int lane)
+{
+#pragma unroll
+    for (int t = 0; t < OT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[((wave * OT + t) * 64 + lane) * 4 + r] = acc[t][r];
+    __syncthreads();
+}
+
 // ------------------------------------------------------------------------------ forward
-template <int OT>   // OT 16-row tiles of output channels per wave
+// One workgroup = one 16-column tile of outputs (all OT channel tiles); its four waves split the
+// contraction (wave w takes k-steps w, w+4, ...) and the partial tiles are summed through LDS in
+// a fixed order.  With one wave per tile the second layer of the reference ((16,16,7,7,14) ->
+// (16,64,3,3,10): only 90 column tiles, K = 2000) ran 23 workgroups of 500 dependent steps.
+template <int OT>   // OT 16-row tiles of output channels
 __global__ __launch_bounds__(BLOCK) void conv3d_fwd_kernel(const float *__restrict__ x,
                                                            const float *__restrict__ w,
                                                            const float *__restrict__ bias,
@@ -52,12 +69,12 @@ __global__ __launch_bounds__(BLOCK) void conv3d_fwd_kernel(const float *__restri
                                                            int Ntot, int relu)
 {
     __shared__ int off[KCHUNK];
+    __shared__ float part[WAVES * OT * 256];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
     const int S = d.OD * d.OH * d.OW;
-    const int tile = blockIdx.x * WAVES + wave;
+    const int tile = blockIdx.x;
     int n = tile * 16 + j;
-    const bool nvalid = n < Ntot;
-    if (!nvalid) n = Ntot - 1;                       // keep the gathers in bounds; never stored
+    if (n >= Ntot) n = Ntot - 1;                     // keep the gathers in bounds; never stored
     const int b_ = n / S, sp = n % S;
     const int ow = sp % d.OW, oh = (sp / d.OW) % d.OH, od = sp / (d.OW * d.OH);
     const size_t nbase = (((size_t)b_ * d.Cin * d.D + od) * d.H + oh) * d.W + ow;
@@ -72,47 +89,59 @@ __global__ __launch_bounds__(BLOCK) void conv3d_fwd_kernel(const float *__restri
         __syncthreads();
         for (int k = tid; k < kn4; k += BLOCK) off[k] = k < kn ? tap_offset(d, kc + k) : 0;
         __syncthreads();
-        for (int k0 = 0; k0 < kn4; k0 += 4) {
-            const int k = k0 + g;
-            const float xv = x[nbase + off[k]];
+        // UNR steps' operands are all requested before the first MFMA consumes one (hipcc does
+        // not unroll a loop around the MFMA builtin by itself, and one step = one L2 round trip)
+        for (int kb = 4 * wave; kb < kn4; kb += 4 * WAVES * UNR) {
+            float xv[UNR], wv[UNR][OT];
 #pragma unroll
-            for (int t = 0; t < OT; ++t) {
-                const int o = t * 16 + j;
-                const float wv = (k < kn && o < d.Cout) ? w[(size_t)o * K + kc + k] : 0.0f;
-                acc[t] = mma(wv, xv, acc[t]);
+            for (int u = 0; u < UNR; ++u) {
+                const int k = kb + u * 4 * WAVES + g;
+                const bool ok = k < kn;
+                const int kk = ok ? k : 0;
+                xv[u] = x[nbase + off[kk]];
+#pragma unroll
+                for (int t = 0; t < OT; ++t) {
+                    const int o = t * 16 + j;
+                    wv[u][t] = (ok && o < d.Cout) ? w[(size_t)o * K + kc + kk] : 0.0f;
+                }
             }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u)
+#pragma unroll
+                for (int t = 0; t < OT; ++t) acc[t] = mma(wv[u][t], xv[u], acc[t]);
         }
     }
-    if (!nvalid) return;
+    reduce_tiles<OT>(part, acc, wave, lane);
+    for (int idx = tid; idx < OT * 256; idx += BLOCK) {
+        const int t = idx >> 8, l = (idx >> 2) & 63, r = idx & 3;
+        const int o = t * 16 + 4 * (l >> 4) + r;
+        const int nn = tile * 16 + (l & 15);
+        if (o >= d.Cout || nn >= Ntot) continue;
+        float v = bias ? bias[o] : 0.0f;
 #pragma unroll
-    for (int t = 0; t < OT; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int o = t * 16 + 4 * g + r;
-            if (o < d.Cout) {
-                float v = acc[t][r] + (bias ? bias[o] : 0.0f);
-                if (relu) v = fmaxf(v, 0.0f);
-                y[((size_t)b_ * d.Cout + o) * S + sp] = v;
-            }
-        }
+        for (int wv = 0; wv < WAVES; ++wv) v += part[((wv * OT + t) * 64 + l) * 4 + r];
+        if (relu) v = fmaxf(v, 0.0f);
+        y[((size_t)(nn / S) * d.Cout + o) * S + nn % S] = v;
+    }
 }
 
 // ------------------------------------------------------------------------------ backward data
-// table entry for kk = (o,kd,kh,kw): o << 24 | kd << 16 | kh << 8 | kw
-template <int CT>   // CT 16-row tiles of input channels per wave
+// table entry for kk = (o,kd,kh,kw): o << 24 | kd << 16 | kh << 8 | kw.  Same decomposition as the
+// forward kernel: one workgroup per 16-position tile, the four waves split the contraction.
+template <int CT>   // CT 16-row tiles of input channels
 __global__ __launch_bounds__(BLOCK) void conv3d_bwd_data_kernel(const float *__restrict__ gy,
                                                                 const float *__restrict__ w,
                                                                 float *__restrict__ gx, Dims3 d,
                                                                 int K2, int Mtot)
 {
     __shared__ int tab[KCHUNK];
+    __shared__ float part[WAVES * CT * 256];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
     const int k3 = d.kD * d.kH * d.kW;
     const int S = d.OD * d.OH * d.OW, V = d.D * d.H * d.W;
-    const int tile = blockIdx.x * WAVES + wave;
+    const int tile = blockIdx.x;
     int m = tile * 16 + j;
-    const bool mvalid = m < Mtot;
-    if (!mvalid) m = Mtot - 1;
+    if (m >= Mtot) m = Mtot - 1;
     const int b_ = m / V, pos = m % V;
     const int pw = pos % d.W, ph = (pos / d.W) % d.H, pd = pos / (d.W * d.H);
     const size_t gybase = (size_t)b_ * d.Cout * S;
@@ -136,31 +165,44 @@ __global__ __launch_bounds__(BLOCK) void conv3d_bwd_data_kernel(const float *__r
             tab[k] = e;
         }
         __syncthreads();
-        for (int k0 = 0; k0 < kn4; k0 += 4) {
-            const int e = tab[k0 + g];
-            const int o = (e >> 24) & 0xff, kd = (e >> 16) & 0xff, kh = (e >> 8) & 0xff,
-                      kw = e & 0xff;
-            const int od = pd - kd, oh = ph - kh, ow = pw - kw;
-            const bool in = e >= 0 && od >= 0 && od < d.OD && oh >= 0 && oh < d.OH && ow >= 0 &&
-                            ow < d.OW;
-            const float gv = in ? gy[gybase + (size_t)o * S + (od * d.OH + oh) * d.OW + ow] : 0.0f;
-            const int wsp = (kd * d.kH + kh) * d.kW + kw;
+        for (int kb = 4 * wave; kb < kn4; kb += 4 * WAVES * UNR) {
+            float gv[UNR], wv[UNR][CT];
 #pragma unroll
-            for (int t = 0; t < CT; ++t) {
-                const int c = t * 16 + j;
-                const float wv = (e >= 0 && c < d.Cin) ? w[((size_t)o * d.Cin + c) * k3 + wsp] : 0.0f;
-                acc[t] = mma(wv, gv, acc[t]);
+            for (int u = 0; u < UNR; ++u) {
+                const int k = kb + u * 4 * WAVES + g;
+                const int e = k < kn4 ? tab[k] : -1;
+                const int o = (e >> 24) & 0x7f, kd = (e >> 16) & 0xff, kh = (e >> 8) & 0xff,
+                          kw = e & 0xff;
+                const int od = pd - kd, oh = ph - kh, ow = pw - kw;
+                const bool in = e >= 0 && od >= 0 && od < d.OD && oh >= 0 && oh < d.OH &&
+                                ow >= 0 && ow < d.OW;
+                // out-of-range taps read element 0 of this batch item's gy (in bounds) times zero
+                const size_t gi = in ? (size_t)o * S + (od * d.OH + oh) * d.OW + ow : 0;
+                gv[u] = in ? gy[gybase + gi] : 0.0f;
+                const int wsp = (kd * d.kH + kh) * d.kW + kw;
+#pragma unroll
+                for (int t = 0; t < CT; ++t) {
+                    const int c = t * 16 + j;
+                    wv[u][t] = (e >= 0 && c < d.Cin) ? w[((size_t)o * d.Cin + c) * k3 + wsp] : 0.0f;
+                }
             }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u)
+#pragma unroll
+                for (int t = 0; t < CT; ++t) acc[t] = mma(wv[u][t], gv[u], acc[t]);
         }
     }
-    if (!mvalid) return;
+    reduce_tiles<CT>(part, acc, wave, lane);
+    for (int idx = tid; idx < CT * 256; idx += BLOCK) {
+        const int t = idx >> 8, l = (idx >> 2) & 63, r = idx & 3;
+        const int c = t * 16 + 4 * (l >> 4) + r;
+        const int mm = tile * 16 + (l & 15);
+        if (c >= d.Cin || mm >= Mtot) continue;
+        float v = 0.0f;
 #pragma unroll
-    for (int t = 0; t < CT; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int c = t * 16 + 4 * g + r;
-            if (c < d.Cin) gx[((size_t)b_ * d.Cin + c) * V + pos] = acc[t][r];
-        }
+        for (int wv = 0; wv < WAVES; ++wv) v += part[((wv * CT + t) * 64 + l) * 4 + r];
+        gx[((size_t)(mm / V) * d.Cin + c) * V + mm % V] = v;
+    }
 }
 
 // ------------------------------------------------------------------------------ backward w, b
@@ -202,13 +244,19 @@ __global__ __launch_bounds__(BLOCK) void conv3d_bwd_wb_kernel(const float *__res
     const size_t a_off = (size_t)o_a * S;
 
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int t0 = 0; t0 < nn4; t0 += 4) {
-        const int t = t0 + g;
-        const bool tv = t < nn;
-        const float gv = (tv && a_ok) ? gy[gbase[t] + a_off] : 0.0f;
-        float xv = 0.0f;
-        if (tv) xv = k_b < K ? x[xbase[t] + koff] : (k_b == K ? 1.0f : 0.0f);
-        acc = mma(gv, xv, acc);
+    for (int tb = 0; tb < nn4; tb += 4 * UNR) {
+        float gv[UNR], xv[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int t = tb + 4 * u + g;
+            const bool tv = t < nn;
+            const int tt = tv ? t : 0;
+            gv[u] = (tv && a_ok) ? gy[gbase[tt] + a_off] : 0.0f;
+            const float xl = x[xbase[tt] + koff];           // koff = 0 for the bias column
+            xv[u] = !tv ? 0.0f : (k_b < K ? xl : (k_b == K ? 1.0f : 0.0f));
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) acc = mma(gv[u], xv[u], acc);
     }
     const int nw = d.Cout * K, nent = nw + d.Cout;
     double *dst = partial + (size_t)blockIdx.y * nent;
@@ -325,7 +373,7 @@ extern "C" int wm_conv3d_fwd_f32(const float *x, const float *w, const float *b,
     WM_REQUIRE(wm_num_cus() > 0, WM_ERR_NO_DEVICE, "wm_conv3d_fwd_f32: no HIP device");
     const int K = Cin * kD * kH * kW;
     const int Ntot = B * d.OD * d.OH * d.OW;
-    const int blocks = ((Ntot + 15) / 16 + WAVES - 1) / WAVES;
+    const int blocks = (Ntot + 15) / 16;            // one workgroup per 16-column tile
     hipStream_t st = (hipStream_t)stream;
     const int ot = (Cout + 15) / 16;
     if (ot == 1)
@@ -351,7 +399,7 @@ extern "C" int wm_conv3d_bwd_data_f32(const float *gy, const float *w, float *gx
     WM_REQUIRE(wm_num_cus() > 0, WM_ERR_NO_DEVICE, "wm_conv3d_bwd_data_f32: no HIP device");
     const int K2 = Cout * kD * kH * kW;
     const int Mtot = B * D * H * W;
-    const int blocks = ((Mtot + 15) / 16 + WAVES - 1) / WAVES;
+    const int blocks = (Mtot + 15) / 16;            // one workgroup per 16-position tile
     hipStream_t st = (hipStream_t)stream;
     const int ct = (Cin + 15) / 16;
     if (ct == 1)
