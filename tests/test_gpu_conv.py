@@ -63,6 +63,16 @@ def test_conv_full_grid_721x1440(conv_golden):
     (3, 1, 33, 130, 1, 5, 5),
     (2, 1, 9, 70, 1, 3, 1), (2, 1, 9, 70, 1, 1, 3), (2, 1, 9, 70, 1, 2, 2),
     (2, 1, 9, 70, 1, 1, 1), (4, 1, 2, 64, 1, 2, 1), (4, 1, 6, 65, 1, 1, 2),
+    # W % 4 == 0: the flat-aligned kernels (LDS ring, shuffle halo, ragged head/tail of a range)
+    (1, 1, 3, 20, 1, 3, 3),       # one output row, OW = 18: last lane stores 2 of 4
+    (5, 1, 40, 68, 1, 3, 3),      # ranges that cross image boundaries
+    (3, 1, 7, 256, 1, 3, 3),      # OW = 254: second wave holds two columns
+    (2, 1, 9, 260, 1, 1, 3), (2, 1, 9, 72, 1, 3, 1), (2, 1, 9, 72, 1, 2, 2),
+    (2, 1, 9, 72, 1, 1, 1), (4, 1, 6, 68, 1, 1, 2), (3, 1, 11, 24, 1, 2, 1),
+    (7, 1, 3, 1024, 1, 3, 3),     # H == kH: one output row per image, every range crosses images
+    (2, 1, 5, 4032, 1, 3, 3),     # 16 waves per row (the widest the flat kernels take)
+    (1, 1, 4, 4100, 1, 3, 3),     # wider: falls back to the strip kernels
+    (1, 1, 1500, 20, 1, 3, 3),    # tall and narrow: hundreds of short ranges
     (1, 1, 7, 7, 1, 7, 7),        # generic path, 1x1 output
     (2, 3, 8, 9, 2, 2, 3),        # generic path, odd everything
 ])
