@@ -162,3 +162,42 @@ def test_dropin_module_reproduces_reference_training(model_golden):
         assert np.abs(v.cpu().numpy() - ref[k]).max() < 2e-5, k
     correct, total, _ = nc.testing_loop([(x[i], y[i]) for i in range(8)], model, loss_fn)
     assert total == 8 and 0 <= correct <= 8
+
+
+def test_device_trainer_matches_module_training():
+    from weather_model_amd import ops
+    """DeviceTrainer (gather + fused train + Adam launches) == the drop-in module trained through
+    torch autograd and torch.optim.Adam on the same batches, and the loss goes down."""
+    import numpy as np
+    from weather_model_amd import synth
+    from weather_model_amd.dropin import newConvolution as nc
+    T, Z, Y, X = 9, 2, 8, 16
+    data = {v: torch.from_numpy(synth.uniform(100 + k, (T, 1, Z, Y, X)))
+            for k, v in enumerate(nc.data_vars)}
+    shape = (T - 6, Z, Y, X)
+    ds = nc.CustomDataset(data, int(np.prod(shape)), shape, 0)
+    torch.manual_seed(3)
+    model_a = nc.CustomModel((2, 6))
+    model_b = nc.CustomModel((2, 6))
+    model_b.load_state_dict(model_a.state_dict())
+    trainer = nc.DeviceTrainer(model_a)
+    l0 = trainer.epoch(ds, batch_size=64, shuffle=False)
+    # the same batches through the module / autograd / torch Adam
+    opt = torch.optim.Adam(model_b.parameters())
+    loss_fn = torch.nn.MSELoss()
+    losses = []
+    for start in range(0, len(ds), 64):
+        x, y = ds.batch(list(range(start, min(start + 64, len(ds)))), device="cuda")
+        loss = loss_fn(model_b(x), y)
+        losses.append(float(loss.detach()))
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+    assert l0 == pytest.approx(float(np.mean(losses)), rel=1e-4)
+    for name, _ in ops.MODEL_PARAM_SHAPES:
+        a = model_a.get_parameter(name).detach().cpu().numpy()
+        b = model_b.get_parameter(name).detach().cpu().numpy()
+        assert np.abs(a - b).max() <= 1e-5 * max(np.abs(b).max(), 1e-3), name
+    l1 = trainer.epoch(ds, batch_size=64, shuffle=True, seed=1)
+    l2 = trainer.epoch(ds, batch_size=64, shuffle=True, seed=2)
+    assert l2 < l0

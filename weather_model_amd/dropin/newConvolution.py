@@ -234,6 +234,64 @@ def testing_loop(data, model, loss_fn):
     return correct, total, total_loss / max(counter, 1)
 
 
+class DeviceTrainer:
+    """Not in the reference: the whole epoch on the GPU.  ``training_loop`` above keeps the
+    reference's shape (a DataLoader feeding ``model(x)`` / ``loss.backward()`` /
+    ``optimizer.step()``, which costs a Python round trip and a host-side gather per batch); this
+    does the same arithmetic -- forward, MSE, backward, Adam -- as three launches per batch
+    (``wm_gather_triplets_f32`` -> ``wm_model_train_f32`` -> ``wm_adam_step_f32``) on a resident
+    volume.  Under an initialised ``torch.distributed`` group every rank takes its share of each
+    batch and the flat gradient is all-reduced once per step."""
+
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        from weather_model_amd import dp
+        self._dp = dp
+        self.model = model
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.flat = model.flat_parameters().detach().clone().contiguous()
+        self.m = torch.zeros_like(self.flat)
+        self.v = torch.zeros_like(self.flat)
+        self.step = 0
+
+    def epoch(self, dataset, batch_size, shuffle=True, seed=0, max_batches=None):
+        """One pass over ``dataset`` (a CustomDataset); returns the mean batch loss."""
+        dev = self.flat.device
+        n = len(dataset)
+        world, rank = self._dp.world(), self._dp.rank()
+        gen = torch.Generator(device="cpu").manual_seed(seed)
+        order = (torch.randperm(n, generator=gen) if shuffle else torch.arange(n)).to(dev)
+        total = torch.zeros((), device=dev)
+        batches = 0
+        for start in range(0, n, batch_size):
+            idx = order[start:start + batch_size]
+            mine = idx[rank::world]                      # this rank's share of the global batch
+            if mine.numel() == 0:
+                continue
+            x, y = dataset.batch(mine, device=dev)
+            _, loss, grads = ops.model_train(self.flat, x, y, batch_global=int(idx.numel()))
+            self._dp.reduce_grads_(grads)
+            self.step += 1
+            ops.adam_step(self.flat, grads, self.m, self.v, self.step, self.lr, self.betas[0],
+                          self.betas[1], self.eps)
+            total += loss
+            batches += 1
+            if max_batches is not None and batches >= max_batches:
+                break
+        if world > 1:
+            self._dp.allreduce_sum_(total)               # per-rank losses are shares of the mean
+        self.sync_to_model()
+        return float(total) / max(batches, 1)
+
+    def sync_to_model(self):
+        """Write the trained flat vector back into the module's parameters."""
+        off = 0
+        with torch.no_grad():
+            for name, shp in ops.MODEL_PARAM_SHAPES:
+                k = prod(shp)
+                self.model.get_parameter(name).copy_(self.flat[off:off + k].reshape(shp))
+                off += k
+
+
 def main(batch_size=1):
     """The reference's script entry (newConvolution.py:219-255); batch_size > 1 uses the batched
     kernels (the reference is fixed at 1)."""
