@@ -729,7 +729,11 @@ extern "C" int wm_normal_solve_f64(const double *acc, int F, int P, int fit_inte
     hipStream_t st = (hipStream_t)stream;
     const size_t bytes = (2 * ((size_t)F * F + (size_t)F * P) + 2 * (size_t)F + P) * sizeof(double);
     if (bytes <= SOLVE_LDS_LIMIT) {
-        static bool attr_set = false;
+        // per device: the attribute belongs to the function's image on the current device
+        static bool attr_set_dev[64] = {};
+        int dev = 0;
+        WM_HIP(hipGetDevice(&dev));
+        bool &attr_set = attr_set_dev[dev & 63];
         if (!attr_set) {
             WM_HIP(hipFuncSetAttribute((const void *)normal_solve_kernel<true>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -605,7 +605,11 @@ int model_launch(const float *prm, const float *x, const float *y, const float *
                  float *gtiles, float *loss_part, long long B, float dscale, int grid,
                  hipStream_t st)
 {
-    static bool attr_set[3] = {false, false, false};
+    // per device: the attribute belongs to the function's image on the current device
+    static bool attr_set_dev[64][3] = {};
+    int dev = 0;
+    WM_HIP(hipGetDevice(&dev));
+    bool (&attr_set)[3] = attr_set_dev[dev & 63];
     if (!attr_set[MODE]) {
         WM_HIP(hipFuncSetAttribute((const void *)model_kernel<MODE>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
