@@ -125,6 +125,95 @@ __global__ __launch_bounds__(BLOCK) void conv3d_fwd_kernel(const float *__restri
     }
 }
 
+// ------------------------------------------------------------------------------ forward, wide
+// For large outputs (the 721 x 1440 grids of BASELINE config 4b): a workgroup owns WIDE_TILES
+// consecutive 16-column tiles, each wave two of them for every channel tile, and the weights of a
+// K-chunk are packed once into LDS in MFMA operand order and reused by all eight column tiles
+// (in the split-K kernel above every wave gathers its weights from L1/L2 per step: 16 scattered
+// lines per operand against 8 cycles per MFMA).
+constexpr int WIDE_TILES = 2 * WAVES;     // column tiles per workgroup
+constexpr int WIDE_STEPS = 32;            // MFMA k-steps (of 4 taps) per LDS chunk
+
+template <int OT>
+__global__ __launch_bounds__(BLOCK) void conv3d_fwd_wide_kernel(const float *__restrict__ x,
+                                                                const float *__restrict__ w,
+                                                                const float *__restrict__ bias,
+                                                                float *__restrict__ y, Dims3 d,
+                                                                int K, int Ntot, int relu)
+{
+    __shared__ int off[WIDE_STEPS * 4];
+    __shared__ float wl[WIDE_STEPS * OT * 64];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
+    const int S = d.OD * d.OH * d.OW;
+    size_t nbase[2];
+    int nn[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        int n = ((int)blockIdx.x * WIDE_TILES + wave + c * WAVES) * 16 + j;
+        nn[c] = n;
+        if (n >= Ntot) n = Ntot - 1;
+        const int b_ = n / S, sp = n % S;
+        const int ow = sp % d.OW, oh = (sp / d.OW) % d.OH, od = sp / (d.OW * d.OH);
+        nbase[c] = (((size_t)b_ * d.Cin * d.D + od) * d.H + oh) * d.W + ow;
+    }
+    f32x4 acc[2][OT];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int t = 0; t < OT; ++t) acc[c][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int kc = 0; kc < K; kc += WIDE_STEPS * 4) {
+        const int kn = min(WIDE_STEPS * 4, K - kc);
+        const int steps = (kn + 3) >> 2;
+        __syncthreads();
+        if (tid < WIDE_STEPS * 4) off[tid] = tid < kn ? tap_offset(d, kc + tid) : 0;
+        // operand (step, t) for lane l: W[o = 16 t + (l & 15)][k = kc + 4 step + (l >> 4)]
+        for (int e = tid; e < steps * OT * 64; e += BLOCK) {
+            const int l = e & 63, q = e >> 6, t = q % OT, st = q / OT;
+            const int o = t * 16 + (l & 15), k = 4 * st + (l >> 4);
+            wl[e] = (k < kn && o < d.Cout) ? w[(size_t)o * K + kc + k] : 0.0f;
+        }
+        __syncthreads();
+        for (int sb = 0; sb < steps; sb += UNR) {
+            float xv[UNR][2];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int st = min(sb + u, steps - 1);        // repeats are multiplied by zero below
+                const int o_ = off[4 * st + g];
+                xv[u][0] = x[nbase[0] + o_];
+                xv[u][1] = x[nbase[1] + o_];
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                if (sb + u < steps) {
+#pragma unroll
+                    for (int t = 0; t < OT; ++t) {
+                        const float a = wl[((sb + u) * OT + t) * 64 + lane];
+                        acc[0][t] = mma(a, xv[u][0], acc[0][t]);
+                        acc[1][t] = mma(a, xv[u][1], acc[1][t]);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        if (nn[c] >= Ntot) continue;
+        const int b_ = nn[c] / S, sp = nn[c] % S;
+#pragma unroll
+        for (int t = 0; t < OT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = t * 16 + 4 * g + r;
+                if (o < d.Cout) {
+                    float v = acc[c][t][r] + (bias ? bias[o] : 0.0f);
+                    if (relu) v = fmaxf(v, 0.0f);
+                    y[((size_t)b_ * d.Cout + o) * S + sp] = v;
+                }
+            }
+    }
+}
+
 // ------------------------------------------------------------------------------ backward data
 // table entry for kk = (o,kd,kh,kw): o << 24 | kd << 16 | kh << 8 | kw.  Same decomposition as the
 // forward kernel: one workgroup per 16-position tile, the four waves split the contraction.
@@ -373,9 +462,23 @@ extern "C" int wm_conv3d_fwd_f32(const float *x, const float *w, const float *b,
     WM_REQUIRE(wm_num_cus() > 0, WM_ERR_NO_DEVICE, "wm_conv3d_fwd_f32: no HIP device");
     const int K = Cin * kD * kH * kW;
     const int Ntot = B * d.OD * d.OH * d.OW;
-    const int blocks = (Ntot + 15) / 16;            // one workgroup per 16-column tile
     hipStream_t st = (hipStream_t)stream;
     const int ot = (Cout + 15) / 16;
+    if (Ntot >= 16 * WIDE_TILES * 2 * wm_num_cus()) {          // enough tiles for two waves of blocks
+        const int wblocks = (Ntot + 16 * WIDE_TILES - 1) / (16 * WIDE_TILES);
+        if (ot == 1)
+            hipLaunchKernelGGL(conv3d_fwd_wide_kernel<1>, dim3(wblocks), dim3(BLOCK), 0, st, x, w, b,
+                               y, d, K, Ntot, relu);
+        else if (ot == 2)
+            hipLaunchKernelGGL(conv3d_fwd_wide_kernel<2>, dim3(wblocks), dim3(BLOCK), 0, st, x, w, b,
+                               y, d, K, Ntot, relu);
+        else
+            hipLaunchKernelGGL(conv3d_fwd_wide_kernel<4>, dim3(wblocks), dim3(BLOCK), 0, st, x, w, b,
+                               y, d, K, Ntot, relu);
+        WM_LAUNCH_CHECK("conv3d_fwd_wide_kernel");
+        return WM_OK;
+    }
+    const int blocks = (Ntot + 15) / 16;            // one workgroup per 16-column tile
     if (ot == 1)
         hipLaunchKernelGGL(conv3d_fwd_kernel<1>, dim3(blocks), dim3(BLOCK), 0, st, x, w, b, y, d, K,
                            Ntot, relu);
