@@ -294,6 +294,102 @@ __global__ __launch_bounds__(BLOCK) void conv3d_bwd_data_kernel(const float *__r
     }
 }
 
+// ------------------------------------------------------------------------------ backward data, wide
+// Same decomposition as conv3d_fwd_wide_kernel for the input gradient of large tensors.
+template <int CT>
+__global__ __launch_bounds__(BLOCK) void conv3d_bwd_data_wide_kernel(const float *__restrict__ gy,
+                                                                     const float *__restrict__ w,
+                                                                     float *__restrict__ gx, Dims3 d,
+                                                                     int K2, int Mtot)
+{
+    __shared__ int tab[WIDE_STEPS * 4];
+    __shared__ float wl[WIDE_STEPS * CT * 64];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
+    const int k3 = d.kD * d.kH * d.kW;
+    const int S = d.OD * d.OH * d.OW, V = d.D * d.H * d.W;
+    int mm[2], pd[2], ph[2], pw[2];
+    size_t gybase[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        int m = ((int)blockIdx.x * WIDE_TILES + wave + c * WAVES) * 16 + j;
+        mm[c] = m;
+        if (m >= Mtot) m = Mtot - 1;
+        const int b_ = m / V, pos = m % V;
+        pw[c] = pos % d.W; ph[c] = (pos / d.W) % d.H; pd[c] = pos / (d.W * d.H);
+        gybase[c] = (size_t)b_ * d.Cout * S;
+    }
+    f32x4 acc[2][CT];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int t = 0; t < CT; ++t) acc[c][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int kc = 0; kc < K2; kc += WIDE_STEPS * 4) {
+        const int kn = min(WIDE_STEPS * 4, K2 - kc);
+        const int steps = (kn + 3) >> 2;
+        __syncthreads();
+        if (tid < WIDE_STEPS * 4) {
+            int e = -1;
+            if (tid < kn) {
+                const int kk = kc + tid;
+                const int o = kk / k3, r = kk % k3;
+                const int kw = r % d.kW, kh = (r / d.kW) % d.kH, kd = r / (d.kW * d.kH);
+                e = (o << 24) | (kd << 16) | (kh << 8) | kw;
+            }
+            tab[tid] = e;
+        }
+        // operand (step, t) for lane l: W[o][c = 16 t + (l & 15)][tap], (o, tap) = kc + 4 step + (l >> 4)
+        for (int e = tid; e < steps * CT * 64; e += BLOCK) {
+            const int l = e & 63, q = e >> 6, t = q % CT, st = q / CT;
+            const int c = t * 16 + (l & 15), k = 4 * st + (l >> 4), kk = kc + k;
+            wl[e] = (k < kn && c < d.Cin) ? w[((size_t)(kk / k3) * d.Cin + c) * k3 + kk % k3] : 0.0f;
+        }
+        __syncthreads();
+        for (int sb = 0; sb < steps; sb += UNR) {
+            float gv[UNR][2];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int st = min(sb + u, steps - 1);
+                const int e = tab[4 * st + g];
+                const int o = (e >> 24) & 0x7f, kd = (e >> 16) & 0xff, kh = (e >> 8) & 0xff,
+                          kw = e & 0xff;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int od = pd[c] - kd, oh = ph[c] - kh, ow = pw[c] - kw;
+                    const bool in = e >= 0 && od >= 0 && od < d.OD && oh >= 0 && oh < d.OH &&
+                                    ow >= 0 && ow < d.OW;
+                    const size_t gi = in ? (size_t)o * S + (od * d.OH + oh) * d.OW + ow : 0;
+                    const float v = gy[gybase[c] + gi];
+                    gv[u][c] = in ? v : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                if (sb + u < steps) {
+#pragma unroll
+                    for (int t = 0; t < CT; ++t) {
+                        const float a = wl[((sb + u) * CT + t) * 64 + lane];
+                        acc[0][t] = mma(a, gv[u][0], acc[0][t]);
+                        acc[1][t] = mma(a, gv[u][1], acc[1][t]);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        if (mm[c] >= Mtot) continue;
+        const int b_ = mm[c] / V, pos = mm[c] % V;
+#pragma unroll
+        for (int t = 0; t < CT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ch = t * 16 + 4 * g + r;
+                if (ch < d.Cin) gx[((size_t)b_ * d.Cin + ch) * V + pos] = acc[c][t][r];
+            }
+    }
+}
+
 // ------------------------------------------------------------------------------ backward w, b
 // grid = (ceil(tiles / WAVES), splits); tile = (o-tile, k-tile) with k in [0, K] (k == K is the
 // bias column of ones).  partial is [splits][nent] float64, nent = Cout*K + Cout.
@@ -502,9 +598,23 @@ extern "C" int wm_conv3d_bwd_data_f32(const float *gy, const float *w, float *gx
     WM_REQUIRE(wm_num_cus() > 0, WM_ERR_NO_DEVICE, "wm_conv3d_bwd_data_f32: no HIP device");
     const int K2 = Cout * kD * kH * kW;
     const int Mtot = B * D * H * W;
-    const int blocks = (Mtot + 15) / 16;            // one workgroup per 16-position tile
     hipStream_t st = (hipStream_t)stream;
     const int ct = (Cin + 15) / 16;
+    if (Mtot >= 16 * WIDE_TILES * 2 * wm_num_cus()) {
+        const int wblocks = (Mtot + 16 * WIDE_TILES - 1) / (16 * WIDE_TILES);
+        if (ct == 1)
+            hipLaunchKernelGGL(conv3d_bwd_data_wide_kernel<1>, dim3(wblocks), dim3(BLOCK), 0, st, gy,
+                               w, gx, d, K2, Mtot);
+        else if (ct == 2)
+            hipLaunchKernelGGL(conv3d_bwd_data_wide_kernel<2>, dim3(wblocks), dim3(BLOCK), 0, st, gy,
+                               w, gx, d, K2, Mtot);
+        else
+            hipLaunchKernelGGL(conv3d_bwd_data_wide_kernel<4>, dim3(wblocks), dim3(BLOCK), 0, st, gy,
+                               w, gx, d, K2, Mtot);
+        WM_LAUNCH_CHECK("conv3d_bwd_data_wide_kernel");
+        return WM_OK;
+    }
+    const int blocks = (Mtot + 15) / 16;            // one workgroup per 16-position tile
     if (ct == 1)
         hipLaunchKernelGGL(conv3d_bwd_data_kernel<1>, dim3(blocks), dim3(BLOCK), 0, st, gy, w, gx, d,
                            K2, Mtot);
