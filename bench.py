@@ -368,6 +368,56 @@ def run_model(steps, warmup, rank, world, cpu_base, B=721 * 1440):
     return res
 
 
+# ------------------------------------------------------------------------------ 32-channel conv
+def run_conv32(steps, warmup, rank, world, cpu_base, N=8, C=32, H=721, W=1440):
+    """BASELINE configs[3] read literally (4b): one Conv(32->32, 3x3) layer on (N,32,721,1440),
+    forward + backward(data, weight, bias) -- the implicit-GEMM MFMA kernels."""
+    from weather_model_amd import ops, dp
+    x = ops.synth_uniform((N, C, H, W), seed=30, offset=rank * N * C * H * W)
+    w = ops.synth_uniform((C, C, 3, 3), seed=31, lo=-1.0 / 17, hi=1.0 / 17)
+    b = ops.synth_uniform((C,), seed=32, lo=-1.0 / 17, hi=1.0 / 17)
+    gy = ops.synth_uniform((N, C, H - 2, W - 2), seed=33, lo=-1.0, hi=1.0,
+                           offset=rank * N * C * (H - 2) * (W - 2))
+    flat = torch.zeros((C * C * 9 + C,), device="cuda")
+    evs = {"fwd": [], "bwd_data": [], "bwd_wb": []}
+
+    def step(i, timed):
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if timed else None
+        if timed:
+            marks[0].record()
+        ops.conv2d_forward(x, w, b)
+        if timed:
+            marks[1].record()
+        ops.conv2d_backward_data(gy, w, x.shape)
+        if timed:
+            marks[2].record()
+        gw, gb = ops.conv2d_backward_wb(x, gy, w.shape)
+        if timed:
+            marks[3].record()
+            for k, (a, c) in zip(evs, zip(marks[:-1], marks[1:])):
+                evs[k].append((a, c))
+        if world > 1:
+            flat[:C * C * 9] = gw.reshape(-1)
+            flat[C * C * 9:] = gb
+            dp.reduce_grads_(flat)
+
+    total = timed_steps(step, steps, warmup, world)
+    ms = {k: float(np.mean([a.elapsed_time(c) for a, c in v])) for k, v in evs.items()}
+    pts = N * H * W
+    flops_pass = 2.0 * C * C * 9 * N * (H - 2) * (W - 2)
+    ach = 3 * flops_pass / (sum(ms.values()) * 1e-3) / 1e12
+    return {"value": pts * world * steps / total, "unit": "grid-pts/s",
+            "ms_per_step": total / steps * 1e3, "kernel_ms": ms,
+            "config": {"workload": f"Conv2d({C}->{C}, 3x3) fwd + bwd(data, weight, bias) on "
+                                   f"({N},{C},{H},{W}) per GPU"},
+            "roofline": {"bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF,
+                         "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF, "traffic": None,
+                         "kernel": "conv3d_fwd_wide_kernel + conv3d_bwd_data_wide_kernel + "
+                                   "conv3d_bwd_wb_wide_kernel",
+                         "algorithmic_flops_per_point_per_pass": 2 * C * C * 9,
+                         "TFLOPs": {k: flops_pass / (v * 1e-3) / 1e12 for k, v in ms.items()}}}
+
+
 # ------------------------------------------------------------------------------ field kernels
 def run_fields(steps, warmup, rank, world, cpu_base):
     """one-pass statistics, normalise and the sample gather, each on a
@@ -447,7 +497,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="all", choices=["all", "gram16", "conv3x3", "gram64", "model32", "fields"])
+    ap.add_argument("--workload", default="all", choices=["all", "gram16", "conv3x3", "gram64", "model32", "fields", "conv32"])
     ap.add_argument("--rows", type=int, default=100_000_000, help="rows per GPU (gram workloads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -498,6 +548,15 @@ def main():
                 out["cpu_baseline"] = mres["cpu_baseline"]
         else:
             out.setdefault("also", {})["model32"] = mres
+    if args.workload in ("all", "conv32"):
+        cres = run_conv32(args.steps, args.warmup, rank, world, cpu_base)
+        if args.workload == "conv32":
+            out.update({"metric": "grid-pts/s conv32 fwd+bwd", "unit": "grid-pts/s",
+                        "value": cres["value"], "ms_per_step": cres["ms_per_step"],
+                        "roofline": cres["roofline"], "config": cres["config"],
+                        "kernel_ms": cres["kernel_ms"]})
+        else:
+            out.setdefault("also", {})["conv32"] = cres
     if args.workload in ("all", "fields"):
         fres = run_fields(args.steps, args.warmup, rank, world, cpu_base)
         if args.workload == "fields":

@@ -75,6 +75,7 @@ def test_conv_full_grid_721x1440(conv_golden):
     (1, 1, 1500, 20, 1, 3, 3),    # tall and narrow: hundreds of short ranges
     (2, 16, 130, 300, 24, 3, 3),  # multi-channel, > 65536 outputs: wide MFMA kernel, ragged Cout
     (1, 20, 70, 1000, 40, 2, 3),  # wide MFMA kernel, ragged Cin, three channel tiles
+    (2, 16, 600, 900, 24, 3, 3),  # > 2^20 outputs: the persistent wide weight-gradient kernel
     (1, 1, 7, 7, 1, 7, 7),        # generic path, 1x1 output
     (2, 3, 8, 9, 2, 2, 3),        # generic path, odd everything
 ])

@@ -133,6 +133,9 @@ __global__ __launch_bounds__(BLOCK) void conv3d_fwd_kernel(const float *__restri
 // lines per operand against 8 cycles per MFMA).
 constexpr int WIDE_TILES = 2 * WAVES;     // column tiles per workgroup
 constexpr int WIDE_STEPS = 32;            // MFMA k-steps (of 4 taps) per LDS chunk
+#ifndef WB_WIDE_BPC
+#define WB_WIDE_BPC 3                     // persistent weight-gradient workgroups per CU
+#endif
 
 template <int OT>
 __global__ __launch_bounds__(BLOCK) void conv3d_fwd_wide_kernel(const float *__restrict__ x,
@@ -455,6 +458,108 @@ __global__ __launch_bounds__(BLOCK) void conv3d_bwd_wb_kernel(const float *__res
     }
 }
 
+// ------------------------------------------------------------------------------ backward w, b, wide
+// For large outputs: persistent workgroups walk chunks of CH outputs.  The gy chunk is staged in
+// LDS once (coalesced) and serves every (channel tile, tap tile) pair; each wave owns the tap
+// tiles wave, wave+4, ... for ALL channel tiles and keeps their accumulators in registers across
+// chunks, so one x gather feeds OT MFMAs (the kernel above gathers both operands per MFMA and
+// re-gathers them for every tile pair).  fp32 accumulators are added into the workgroup's float64
+// slab every FLUSH chunks (<= 1024 products per accumulator, as elsewhere) -- only the owning lane
+// touches an entry, so there are no atomics; the slabs are summed by conv3d_reduce_kernel.
+template <int OT, int KTW>
+__global__ __launch_bounds__(BLOCK) void conv3d_bwd_wb_wide_kernel(const float *__restrict__ x,
+                                                                   const float *__restrict__ gy,
+                                                                   double *__restrict__ slabs,
+                                                                   Dims3 d, int K, int Ntot,
+                                                                   int ktiles)
+{
+    constexpr int CH = OT == 4 ? 128 : 256;
+    constexpr int GP = CH + 2;                    // row pitch: conflict-free (o, n) operand reads
+    constexpr int FLUSH = 1024 / CH;
+    __shared__ int xbase[CH];
+    __shared__ int gbase[CH];
+    __shared__ float gl[OT * 16 * GP];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
+    const int S = d.OD * d.OH * d.OW;
+    const int nw = d.Cout * K, nent = nw + d.Cout;
+    double *slab = slabs + (size_t)blockIdx.x * nent;
+
+    int koff[KTW];
+#pragma unroll
+    for (int q = 0; q < KTW; ++q) {
+        const int k_b = (wave + WAVES * q) * 16 + j;
+        koff[q] = k_b < K ? tap_offset(d, k_b) : 0;
+    }
+    f32x4 acc[KTW][OT];
+#pragma unroll
+    for (int q = 0; q < KTW; ++q)
+#pragma unroll
+        for (int t = 0; t < OT; ++t) acc[q][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nchunks = (Ntot + CH - 1) / CH;
+    int pending = 0;
+    for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        const int n0 = chunk * CH;
+        const int nn = min(CH, Ntot - n0);
+        __syncthreads();
+        if (tid < CH) {
+            int xb = 0, gb = 0;
+            if (tid < nn) {
+                const int n = n0 + tid;
+                const int b_ = n / S, sp = n % S;
+                const int ow = sp % d.OW, oh = (sp / d.OW) % d.OH, od = sp / (d.OW * d.OH);
+                xb = ((b_ * d.Cin * d.D + od) * d.H + oh) * d.W + ow;
+                gb = b_ * d.Cout * S + sp;
+            }
+            xbase[tid] = xb;
+            gbase[tid] = gb;
+        }
+        __syncthreads();
+        for (int e = tid; e < OT * 16 * CH; e += BLOCK) {
+            const int o = e / CH, t = e % CH;
+            gl[o * GP + t] = (t < nn && o < d.Cout) ? gy[gbase[t] + (size_t)o * S] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < KTW; ++q) {
+            const int kt = wave + WAVES * q;
+            if (kt >= ktiles) continue;                       // uniform per wave
+            const int k_b = kt * 16 + j;
+            for (int tb = 0; tb < CH; tb += 4 * UNR) {
+                float xv[UNR];
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const float xl = x[xbase[tb + 4 * u + g] + koff[q]];
+                    xv[u] = k_b < K ? xl : (k_b == K ? 1.0f : 0.0f);   // gy is zero past the end
+                }
+#pragma unroll
+                for (int u = 0; u < UNR; ++u)
+#pragma unroll
+                    for (int t = 0; t < OT; ++t)
+                        acc[q][t] = mma(gl[(t * 16 + j) * GP + tb + 4 * u + g], xv[u], acc[q][t]);
+            }
+        }
+        if (++pending == FLUSH || chunk + (int)gridDim.x >= nchunks) {
+            pending = 0;
+#pragma unroll
+            for (int q = 0; q < KTW; ++q) {
+                const int k_b = (wave + WAVES * q) * 16 + j;
+#pragma unroll
+                for (int t = 0; t < OT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int o = t * 16 + 4 * g + r;
+                        if (o < d.Cout) {
+                            if (k_b < K) slab[(size_t)o * K + k_b] += (double)acc[q][t][r];
+                            else if (k_b == K) slab[nw + o] += (double)acc[q][t][r];
+                        }
+                        acc[q][t][r] = 0.0f;
+                    }
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(64) void conv3d_reduce_kernel(const double *__restrict__ partial,
                                                            int nparts, int nent, int nw,
                                                            float *__restrict__ gw,
@@ -523,6 +628,14 @@ __global__ __launch_bounds__(BLOCK) void maxpool3d_bwd_kernel(const float *__res
         }
         gx[i] = v;
     }
+}
+
+// the wide weight-gradient kernel: enough outputs to keep persistent workgroups busy and at most
+// 8 tap tiles per wave (accumulators live in registers)
+bool wb_wide_shape(long long Ntot, int K)
+{
+    const int cus = wm_num_cus();
+    return cus > 0 && Ntot >= 4096ll * cus && (K + 1 + 15) / 16 <= 8 * WAVES;
 }
 
 int fill_dims(Dims3 *d, int B, int Cin, int D, int H, int W, int Cout, int kD, int kH, int kW)
@@ -635,8 +748,9 @@ extern "C" size_t wm_conv3d_bwd_wb_workspace_bytes(int B, int Cin, int D, int H,
         kW <= 0 || kD > D || kH > H || kW > W)
         return 0;
     const long long Ntot = (long long)B * (D - kD + 1) * (H - kH + 1) * (W - kW + 1);
-    const size_t splits = (size_t)((Ntot + NCHUNK - 1) / NCHUNK);
+    size_t splits = (size_t)((Ntot + NCHUNK - 1) / NCHUNK);
     const size_t nent = (size_t)Cout * Cin * kD * kH * kW + Cout;
+    if (wb_wide_shape(Ntot, Cin * kD * kH * kW)) splits = (size_t)wm_num_cus() * WB_WIDE_BPC;   // one slab per workgroup
     return wm_align_up(splits * nent * sizeof(double), 256);
 }
 
@@ -660,6 +774,29 @@ extern "C" int wm_conv3d_bwd_wb_f32(const float *x, const float *gy, float *gw, 
     const int tiles = ktiles * otiles;
     const int nw = Cout * K, nent = nw + Cout;
     hipStream_t st = (hipStream_t)stream;
+    if (wb_wide_shape(Ntot, K)) {
+        const int grid = wm_num_cus() * WB_WIDE_BPC;
+        WM_HIP(hipMemsetAsync(workspace, 0, (size_t)grid * nent * sizeof(double), st));
+        const int ktw = (ktiles + WAVES - 1) / WAVES;          // tap tiles per wave, 1..8
+#define WB_WIDE(OT_, KTW_)                                                                     \
+    hipLaunchKernelGGL((conv3d_bwd_wb_wide_kernel<OT_, KTW_>), dim3(grid), dim3(BLOCK), 0, st, \
+                       x, gy, (double *)workspace, d, K, Ntot, ktiles)
+#define WB_WIDE_K(OT_)                                \
+    if (ktw <= 2) WB_WIDE(OT_, 2);                    \
+    else if (ktw <= 4) WB_WIDE(OT_, 4);               \
+    else if (ktw <= 6) WB_WIDE(OT_, 6);               \
+    else WB_WIDE(OT_, 8)
+        if (otiles == 1) { WB_WIDE_K(1); }
+        else if (otiles == 2) { WB_WIDE_K(2); }
+        else { WB_WIDE_K(4); }
+#undef WB_WIDE_K
+#undef WB_WIDE
+        WM_LAUNCH_CHECK("conv3d_bwd_wb_wide_kernel");
+        hipLaunchKernelGGL(conv3d_reduce_kernel, dim3((nent + 63) / 64), dim3(64), 0, st,
+                           (const double *)workspace, grid, nent, nw, gw, gb);
+        WM_LAUNCH_CHECK("conv3d_reduce_kernel");
+        return WM_OK;
+    }
     hipLaunchKernelGGL(conv3d_bwd_wb_kernel, dim3((tiles + WAVES - 1) / WAVES, splits), dim3(BLOCK),
                        0, st, x, gy, (double *)workspace, d, K, Ntot, ktiles, tiles);
     WM_LAUNCH_CHECK("conv3d_bwd_wb_kernel");
