@@ -73,8 +73,8 @@ def test_conv_full_grid_721x1440(conv_golden):
     (2, 1, 5, 4032, 1, 3, 3),     # 16 waves per row (the widest the flat kernels take)
     (1, 1, 4, 4100, 1, 3, 3),     # wider: falls back to the strip kernels
     (1, 1, 1500, 20, 1, 3, 3),    # tall and narrow: hundreds of short ranges
-    (2, 16, 130, 300, 24, 3, 3),  # multi-channel, > 65536 outputs: wide MFMA kernel, ragged Cout
-    (1, 20, 70, 1000, 40, 2, 3),  # wide MFMA kernel, ragged Cin, three channel tiles
+    (2, 16, 200, 400, 24, 3, 3),  # multi-channel, > 131072 outputs: wide MFMA kernel, ragged Cout
+    (1, 20, 140, 1000, 40, 2, 3), # wide MFMA kernel, ragged Cin, three channel tiles
     (2, 16, 600, 900, 24, 3, 3),  # > 2^20 outputs: the persistent wide weight-gradient kernel
     (1, 1, 7, 7, 1, 7, 7),        # generic path, 1x1 output
     (2, 3, 8, 9, 2, 2, 3),        # generic path, odd everything

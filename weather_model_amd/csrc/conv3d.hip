@@ -127,11 +127,12 @@ __global__ __launch_bounds__(BLOCK) void conv3d_fwd_kernel(const float *__restri
 
 // ------------------------------------------------------------------------------ forward, wide
 // For large outputs (the 721 x 1440 grids of BASELINE config 4b): a workgroup owns WIDE_TILES
-// consecutive 16-column tiles, each wave two of them for every channel tile, and the weights of a
-// K-chunk are packed once into LDS in MFMA operand order and reused by all eight column tiles
+// consecutive 16-column tiles, each wave CPW of them for every channel tile, and the weights of a
+// K-chunk are packed once into LDS in MFMA operand order and reused by all sixteen column tiles
 // (in the split-K kernel above every wave gathers its weights from L1/L2 per step: 16 scattered
 // lines per operand against 8 cycles per MFMA).
-constexpr int WIDE_TILES = 2 * WAVES;     // column tiles per workgroup
+constexpr int CPW = 4;                    // column tiles per wave
+constexpr int WIDE_TILES = CPW * WAVES;   // column tiles per workgroup
 constexpr int WIDE_STEPS = 32;            // MFMA k-steps (of 4 taps) per LDS chunk
 #ifndef WB_WIDE_BPC
 #define WB_WIDE_BPC 3                     // persistent weight-gradient workgroups per CU
@@ -148,10 +149,10 @@ __global__ __launch_bounds__(BLOCK) void conv3d_fwd_wide_kernel(const float *__r
     __shared__ float wl[WIDE_STEPS * OT * 64];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
     const int S = d.OD * d.OH * d.OW;
-    size_t nbase[2];
-    int nn[2];
+    size_t nbase[CPW];
+    int nn[CPW];
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
+    for (int c = 0; c < CPW; ++c) {
         int n = ((int)blockIdx.x * WIDE_TILES + wave + c * WAVES) * 16 + j;
         nn[c] = n;
         if (n >= Ntot) n = Ntot - 1;
@@ -159,9 +160,9 @@ __global__ __launch_bounds__(BLOCK) void conv3d_fwd_wide_kernel(const float *__r
         const int ow = sp % d.OW, oh = (sp / d.OW) % d.OH, od = sp / (d.OW * d.OH);
         nbase[c] = (((size_t)b_ * d.Cin * d.D + od) * d.H + oh) * d.W + ow;
     }
-    f32x4 acc[2][OT];
+    f32x4 acc[CPW][OT];
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+    for (int c = 0; c < CPW; ++c)
 #pragma unroll
         for (int t = 0; t < OT; ++t) acc[c][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -178,13 +179,13 @@ __global__ __launch_bounds__(BLOCK) void conv3d_fwd_wide_kernel(const float *__r
         }
         __syncthreads();
         for (int sb = 0; sb < steps; sb += UNR) {
-            float xv[UNR][2];
+            float xv[UNR][CPW];
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
-                const int st = min(sb + u, steps - 1);        // repeats are multiplied by zero below
+                const int st = min(sb + u, steps - 1);        // repeats are skipped below
                 const int o_ = off[4 * st + g];
-                xv[u][0] = x[nbase[0] + o_];
-                xv[u][1] = x[nbase[1] + o_];
+#pragma unroll
+                for (int c = 0; c < CPW; ++c) xv[u][c] = x[nbase[c] + o_];
             }
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
@@ -192,15 +193,15 @@ __global__ __launch_bounds__(BLOCK) void conv3d_fwd_wide_kernel(const float *__r
 #pragma unroll
                     for (int t = 0; t < OT; ++t) {
                         const float a = wl[((sb + u) * OT + t) * 64 + lane];
-                        acc[0][t] = mma(a, xv[u][0], acc[0][t]);
-                        acc[1][t] = mma(a, xv[u][1], acc[1][t]);
+#pragma unroll
+                        for (int c = 0; c < CPW; ++c) acc[c][t] = mma(a, xv[u][c], acc[c][t]);
                     }
                 }
             }
         }
     }
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
+    for (int c = 0; c < CPW; ++c) {
         if (nn[c] >= Ntot) continue;
         const int b_ = nn[c] / S, sp = nn[c] % S;
 #pragma unroll
@@ -310,10 +311,10 @@ __global__ __launch_bounds__(BLOCK) void conv3d_bwd_data_wide_kernel(const float
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
     const int k3 = d.kD * d.kH * d.kW;
     const int S = d.OD * d.OH * d.OW, V = d.D * d.H * d.W;
-    int mm[2], pd[2], ph[2], pw[2];
-    size_t gybase[2];
+    int mm[CPW], pd[CPW], ph[CPW], pw[CPW];
+    size_t gybase[CPW];
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
+    for (int c = 0; c < CPW; ++c) {
         int m = ((int)blockIdx.x * WIDE_TILES + wave + c * WAVES) * 16 + j;
         mm[c] = m;
         if (m >= Mtot) m = Mtot - 1;
@@ -321,9 +322,9 @@ __global__ __launch_bounds__(BLOCK) void conv3d_bwd_data_wide_kernel(const float
         pw[c] = pos % d.W; ph[c] = (pos / d.W) % d.H; pd[c] = pos / (d.W * d.H);
         gybase[c] = (size_t)b_ * d.Cout * S;
     }
-    f32x4 acc[2][CT];
+    f32x4 acc[CPW][CT];
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+    for (int c = 0; c < CPW; ++c)
 #pragma unroll
         for (int t = 0; t < CT; ++t) acc[c][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(BLOCK) void conv3d_bwd_data_wide_kernel(const float
         }
         __syncthreads();
         for (int sb = 0; sb < steps; sb += UNR) {
-            float gv[UNR][2];
+            float gv[UNR][CPW];
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
                 const int st = min(sb + u, steps - 1);
@@ -357,7 +358,7 @@ __global__ __launch_bounds__(BLOCK) void conv3d_bwd_data_wide_kernel(const float
                 const int o = (e >> 24) & 0x7f, kd = (e >> 16) & 0xff, kh = (e >> 8) & 0xff,
                           kw = e & 0xff;
 #pragma unroll
-                for (int c = 0; c < 2; ++c) {
+                for (int c = 0; c < CPW; ++c) {
                     const int od = pd[c] - kd, oh = ph[c] - kh, ow = pw[c] - kw;
                     const bool in = e >= 0 && od >= 0 && od < d.OD && oh >= 0 && oh < d.OH &&
                                     ow >= 0 && ow < d.OW;
@@ -372,15 +373,15 @@ __global__ __launch_bounds__(BLOCK) void conv3d_bwd_data_wide_kernel(const float
 #pragma unroll
                     for (int t = 0; t < CT; ++t) {
                         const float a = wl[((sb + u) * CT + t) * 64 + lane];
-                        acc[0][t] = mma(a, gv[u][0], acc[0][t]);
-                        acc[1][t] = mma(a, gv[u][1], acc[1][t]);
+#pragma unroll
+                        for (int c = 0; c < CPW; ++c) acc[c][t] = mma(a, gv[u][c], acc[c][t]);
                     }
                 }
             }
         }
     }
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
+    for (int c = 0; c < CPW; ++c) {
         if (mm[c] >= Mtot) continue;
         const int b_ = mm[c] / V, pos = mm[c] % V;
 #pragma unroll
