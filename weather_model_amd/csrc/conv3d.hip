@@ -477,6 +477,7 @@ __global__ __launch_bounds__(BLOCK) void conv3d_bwd_wb_wide_kernel(const float *
     constexpr int CH = OT == 4 ? 128 : 256;
     constexpr int GP = CH + 2;                    // row pitch: conflict-free (o, n) operand reads
     constexpr int FLUSH = 1024 / CH;
+    constexpr int UNW = 8;                        // x gathers in flight per wave
     __shared__ int xbase[CH];
     __shared__ int gbase[CH];
     __shared__ float gl[OT * 16 * GP];
@@ -526,15 +527,15 @@ __global__ __launch_bounds__(BLOCK) void conv3d_bwd_wb_wide_kernel(const float *
             const int kt = wave + WAVES * q;
             if (kt >= ktiles) continue;                       // uniform per wave
             const int k_b = kt * 16 + j;
-            for (int tb = 0; tb < CH; tb += 4 * UNR) {
-                float xv[UNR];
+            for (int tb = 0; tb < CH; tb += 4 * UNW) {
+                float xv[UNW];
 #pragma unroll
-                for (int u = 0; u < UNR; ++u) {
+                for (int u = 0; u < UNW; ++u) {
                     const float xl = x[xbase[tb + 4 * u + g] + koff[q]];
                     xv[u] = k_b < K ? xl : (k_b == K ? 1.0f : 0.0f);   // gy is zero past the end
                 }
 #pragma unroll
-                for (int u = 0; u < UNR; ++u)
+                for (int u = 0; u < UNW; ++u)
 #pragma unroll
                     for (int t = 0; t < OT; ++t)
                         acc[q][t] = mma(gl[(t * 16 + j) * GP + tb + 4 * u + g], xv[u], acc[q][t]);
