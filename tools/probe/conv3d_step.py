@@ -20,3 +20,11 @@ for i in range(n):
     m.train_step((x1, x2, y))
 torch.cuda.synchronize()
 print(f"train_step {1e3 * (time.perf_counter() - t0) / n:.3f} ms (batch 16)")
+for i in range(3):
+    m.graphed_train_step((x1, x2, y))
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for i in range(n):
+    m.graphed_train_step((x1, x2, y))
+torch.cuda.synchronize()
+print(f"graphed_train_step {1e3 * (time.perf_counter() - t0) / n:.3f} ms (batch 16)")
