@@ -218,6 +218,129 @@ __global__ __launch_bounds__(BLOCK) void conv3d_fwd_wide_kernel(const float *__r
     }
 }
 
+// ------------------------------------------------------------------------------ forward, rows
+// The kernel for the large grids (BASELINE config 4b: 32 -> 32 channels, 3x3, 721 x 1440).
+// Persistent workgroups; the whole packed weight matrix stays in LDS (36 KB for that shape) and
+// there is no barrier after the pack.  A wave's unit of work is 64 consecutive outputs of ONE
+// output row (the last segment of a row is shifted left to end at the row's end and recomputes a
+// few columns), so the position decode is two scalar divisions per unit instead of five vector
+// divisions per column tile, the four column tiles of the wave are immediate offsets of one
+// address, and every store instruction covers whole 64-byte runs of four channels' rows.
+// Operand gathers are double-buffered by hand (set A in flight while set B feeds the MFMAs;
+// hipcc does not pipeline across the MFMA builtin and otherwise sinks each load to its use).
+// Workgroups of one XCD (blockIdx & 7) walk one contiguous eighth of the units, so the kH-fold
+// re-read of the input rows is served by that XCD's L2.
+constexpr int RESIDENT_LDS = 64 * 1024;
+constexpr int ROWS_SEG = 16 * CPW;            // outputs per wave unit
+
+__host__ __device__ inline int rows_steps(int K2) { return ((K2 + 3) >> 2) + 2 * UNR - 1 & ~(2 * UNR - 1); }
+__host__ __device__ inline size_t rows_lds_bytes(int K2, int tiles)
+{
+    const size_t steps = (size_t)rows_steps(K2);
+    return steps * tiles * 64 * sizeof(float) + steps * 4 * sizeof(int);
+}
+
+#define ROWS_LOAD(dst, sbase)                                                          \
+    _Pragma("unroll") for (int u = 0; u < UNR; ++u) {                                  \
+        const unsigned a_ = lane0 + off[4 * ((sbase) + u) + g];                        \
+        _Pragma("unroll") for (int c = 0; c < CPW; ++c)                                \
+            dst[u][c] = *(const float *)(xb + a_ + 64u * c);                           \
+    }
+#define ROWS_MMA(src, sbase)                                                           \
+    _Pragma("unroll") for (int u = 0; u < UNR; ++u)                                    \
+        _Pragma("unroll") for (int t = 0; t < OT; ++t) {                               \
+            const float a = wl[(((sbase) + u) * OT + t) * 64 + lane];                  \
+            _Pragma("unroll") for (int c = 0; c < CPW; ++c)                            \
+                acc[c][t] = mma(a, src[u][c], acc[c][t]);                              \
+        }
+
+template <int OT>
+__global__ __launch_bounds__(BLOCK) void conv3d_fwd_rows_kernel(const float *__restrict__ x,
+                                                                const float *__restrict__ w,
+                                                                const float *__restrict__ bias,
+                                                                float *__restrict__ y, Dims3 d,
+                                                                int K, int relu)
+{
+    extern __shared__ __align__(16) float smem[];
+    const int steps = rows_steps(K);                          // padded with zero weights
+    float *wl = smem;
+    unsigned *off = (unsigned *)(smem + (size_t)steps * OT * 64);   // byte offsets of the taps
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned S = (unsigned)(d.OD * d.OH * d.OW);
+
+    for (int k = tid; k < steps * 4; k += BLOCK) off[k] = k < K ? 4u * (unsigned)tap_offset(d, k) : 0u;
+    for (int e = tid; e < steps * OT * 64; e += BLOCK) wl[e] = 0.0f;
+    __syncthreads();
+    // operand (step, t) for lane l: W[o = 16 t + (l & 15)][k = 4 step + (l >> 4)]; read in row order
+    for (int e = tid; e < d.Cout * K; e += BLOCK) {
+        const int o = e / K, k = e - o * K;
+        wl[((k >> 2) * OT + (o >> 4)) * 64 + (k & 3) * 16 + (o & 15)] = w[e];
+    }
+    __syncthreads();
+
+    float bv[OT][4];                                      // this lane's output channels' biases
+#pragma unroll
+    for (int t = 0; t < OT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int o = t * 16 + 4 * g + r;
+            bv[t][r] = (bias && o < d.Cout) ? bias[o] : 0.0f;
+        }
+    const int segs = (d.OW + ROWS_SEG - 1) / ROWS_SEG;
+    const int units = d.B * d.OD * d.OH * segs;
+    const int groups = (units + WAVES - 1) / WAVES;
+    const int gpx = (groups + 7) >> 3;
+    const int xcd = blockIdx.x & 7, nslot = gridDim.x >> 3;
+    const int gend = min(groups, (xcd + 1) * gpx);
+    const size_t xsample = (size_t)d.Cin * d.D * d.H * d.W, ysample = (size_t)d.Cout * S;
+    for (int grp = xcd * gpx + ((int)blockIdx.x >> 3); grp < gend; grp += nslot) {
+        const int unit = grp * WAVES + wave;
+        if (unit >= units) continue;                       // wave-uniform; no barrier below
+        const int row = unit / segs, seg = unit - row * segs;
+        const int ow0 = min(seg * ROWS_SEG, d.OW - ROWS_SEG);
+        const int oh = row % d.OH, q = row / d.OH, od = q % d.OD, b_ = q / d.OD;
+        const char *xb = (const char *)(x + (size_t)b_ * xsample);
+        const unsigned lane0 = 4u * (unsigned)((od * d.H + oh) * d.W + ow0 + j);
+
+        f32x4 acc[CPW][OT];
+#pragma unroll
+        for (int c = 0; c < CPW; ++c)
+#pragma unroll
+            for (int t = 0; t < OT; ++t) acc[c][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        float xa[UNR][CPW], xc[UNR][CPW];
+        ROWS_LOAD(xa, 0)
+        for (int sb = 0; sb < steps; sb += 2 * UNR) {
+            ROWS_LOAD(xc, sb + UNR)
+            __builtin_amdgcn_sched_barrier(0);
+            ROWS_MMA(xa, sb)
+            __builtin_amdgcn_sched_barrier(0);
+            const int nx_ = sb + 2 * UNR < steps ? sb + 2 * UNR : sb;     // last round: unused re-read
+            ROWS_LOAD(xa, nx_)
+            __builtin_amdgcn_sched_barrier(0);
+            ROWS_MMA(xc, sb + UNR)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        char *yb = (char *)(y + (size_t)b_ * ysample);
+        const unsigned sp0 = 4u * ((unsigned)((od * d.OH + oh) * d.OW + ow0 + j) + (unsigned)(4 * g) * S);
+#pragma unroll
+        for (int t = 0; t < OT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = t * 16 + 4 * g + r;
+                if (o < d.Cout) {
+                    const unsigned yo = sp0 + 4u * (unsigned)(t * 16 + r) * S;
+#pragma unroll
+                    for (int c = 0; c < CPW; ++c) {
+                        float v = acc[c][t][r] + bv[t][r];
+                        if (relu) v = fmaxf(v, 0.0f);
+                        *(float *)(yb + yo + 64u * c) = v;
+                    }
+                }
+            }
+    }
+}
+
 // ------------------------------------------------------------------------------ backward data
 // table entry for kk = (o,kd,kh,kw): o << 24 | kd << 16 | kh << 8 | kw.  Same decomposition as the
 // forward kernel: one workgroup per 16-position tile, the four waves split the contraction.
@@ -390,6 +513,136 @@ __global__ __launch_bounds__(BLOCK) void conv3d_bwd_data_wide_kernel(const float
             for (int r = 0; r < 4; ++r) {
                 const int ch = t * 16 + 4 * g + r;
                 if (ch < d.Cin) gx[((size_t)b_ * d.Cin + ch) * V + pos] = acc[c][t][r];
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------ backward data, rows
+// Input gradient with the tiling of conv3d_fwd_rows_kernel: a wave's unit is 64 consecutive
+// positions of one row of gx.  Units whose every tap is in range for every lane (all but the
+// first/last kH-1 rows and the first and last segment of a row) take the unmasked path; border
+// units evaluate the range per tap and lane.  Tap offsets into gy are negative-going and kept as
+// wrapped 32-bit byte offsets.
+#define ROWSB_LOAD(dst, sbase)                                                         \
+    _Pragma("unroll") for (int u = 0; u < UNR; ++u) {                                  \
+        const int k4_ = 4 * ((sbase) + u) + g;                                         \
+        const unsigned a_ = lane0 + off[k4_];                                          \
+        if (!MASKED) {                                                                 \
+            _Pragma("unroll") for (int c = 0; c < CPW; ++c)                            \
+                dst[u][c] = *(const float *)(gb + a_ + 64u * c);                       \
+        } else {                                                                       \
+            const unsigned tp_ = tap[k4_];                                             \
+            const bool rv_ = (unsigned)(dz - (int)(tp_ >> 16)) < (unsigned)d.OD &&     \
+                             (unsigned)(h - (int)((tp_ >> 8) & 255u)) < (unsigned)d.OH; \
+            const int wq_ = w0 + j - (int)(tp_ & 255u);                                \
+            _Pragma("unroll") for (int c = 0; c < CPW; ++c) {                          \
+                const bool ok_ = rv_ && (unsigned)(wq_ + 16 * c) < (unsigned)d.OW;     \
+                const float v_ = *(const float *)(gb + (ok_ ? a_ + 64u * c : 0u));     \
+                dst[u][c] = ok_ ? v_ : 0.0f;                                           \
+            }                                                                          \
+        }                                                                              \
+    }
+
+template <int CT, bool MASKED>
+__device__ __forceinline__ void bwd_rows_unit(const char *gb, const float *wl, const unsigned *off,
+                                              const unsigned *tap, const Dims3 &d, int steps,
+                                              unsigned lane0, int dz, int h, int w0, int lane,
+                                              f32x4 (&acc)[CPW][CT])
+{
+    constexpr int OT = CT;                                // ROWS_MMA's tile count
+    const int j = lane & 15, g = lane >> 4;
+    float xa[UNR][CPW], xc[UNR][CPW];
+    ROWSB_LOAD(xa, 0)
+    for (int sb = 0; sb < steps; sb += 2 * UNR) {
+        ROWSB_LOAD(xc, sb + UNR)
+        __builtin_amdgcn_sched_barrier(0);
+        ROWS_MMA(xa, sb)
+        __builtin_amdgcn_sched_barrier(0);
+        const int nx_ = sb + 2 * UNR < steps ? sb + 2 * UNR : sb;
+        ROWSB_LOAD(xa, nx_)
+        __builtin_amdgcn_sched_barrier(0);
+        ROWS_MMA(xc, sb + UNR)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int CT>
+__global__ __launch_bounds__(BLOCK) void conv3d_bwd_data_rows_kernel(const float *__restrict__ gy,
+                                                                     const float *__restrict__ w,
+                                                                     float *__restrict__ gx, Dims3 d,
+                                                                     int K2)
+{
+    extern __shared__ __align__(16) float smem[];
+    const int steps = rows_steps(K2);
+    float *wl = smem;
+    unsigned *off = (unsigned *)(smem + (size_t)steps * CT * 64);
+    unsigned *tap = off + steps * 4;
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int k3 = d.kD * d.kH * d.kW;
+    const unsigned S = (unsigned)(d.OD * d.OH * d.OW), V = (unsigned)(d.D * d.H * d.W);
+
+    for (int k = tid; k < steps * 4; k += BLOCK) {
+        unsigned o_ = 0u, t_ = 0u;                        // padding: weight 0, in-range address
+        if (k < K2) {
+            const int o = k / k3, r = k % k3;
+            const int kw = r % d.kW, kh = (r / d.kW) % d.kH, kd = r / (d.kW * d.kH);
+            o_ = 4u * (unsigned)(((o * d.OD - kd) * d.OH - kh) * d.OW - kw);
+            t_ = (unsigned)(kd << 16 | kh << 8 | kw);
+        }
+        off[k] = o_;
+        tap[k] = t_;
+    }
+    for (int e = tid; e < steps * CT * 64; e += BLOCK) wl[e] = 0.0f;
+    __syncthreads();
+    // operand (step, t) for lane l: W[o][c = 16 t + (l & 15)][tap], (o, tap) = 4 step + (l >> 4)
+    for (int e = tid; e < d.Cout * d.Cin * k3; e += BLOCK) {
+        const int oc = e / k3, tv = e - oc * k3, o = oc / d.Cin, c = oc - o * d.Cin;
+        const int kk = o * k3 + tv;
+        wl[((kk >> 2) * CT + (c >> 4)) * 64 + (kk & 3) * 16 + (c & 15)] = w[e];
+    }
+    __syncthreads();
+
+    const int segs = (d.W + ROWS_SEG - 1) / ROWS_SEG;
+    const int units = d.B * d.D * d.H * segs;
+    const int groups = (units + WAVES - 1) / WAVES;
+    const int gpx = (groups + 7) >> 3;
+    const int xcd = blockIdx.x & 7, nslot = gridDim.x >> 3;
+    const int gend = min(groups, (xcd + 1) * gpx);
+    const size_t gysample = (size_t)d.Cout * S, gxsample = (size_t)d.Cin * V;
+    for (int grp = xcd * gpx + ((int)blockIdx.x >> 3); grp < gend; grp += nslot) {
+        const int unit = grp * WAVES + wave;
+        if (unit >= units) continue;                       // wave-uniform; no barrier below
+        const int row = unit / segs, seg = unit - row * segs;
+        const int w0 = min(seg * ROWS_SEG, d.W - ROWS_SEG);
+        const int h = row % d.H, q = row / d.H, dz = q % d.D, b_ = q / d.D;
+        const char *gb = (const char *)(gy + (size_t)b_ * gysample);
+        const unsigned lane0 = 4u * (unsigned)((dz * d.OH + h) * d.OW + w0 + j);   // wraps with off[]
+
+        f32x4 acc[CPW][CT];
+#pragma unroll
+        for (int c = 0; c < CPW; ++c)
+#pragma unroll
+            for (int t = 0; t < CT; ++t) acc[c][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const bool interior = dz >= d.kD - 1 && dz < d.OD && h >= d.kH - 1 && h < d.OH &&
+                              w0 >= d.kW - 1 && w0 + ROWS_SEG <= d.OW;
+        if (interior)
+            bwd_rows_unit<CT, false>(gb, wl, off, tap, d, steps, lane0, dz, h, w0, lane, acc);
+        else
+            bwd_rows_unit<CT, true>(gb, wl, off, tap, d, steps, lane0, dz, h, w0, lane, acc);
+
+        char *xb = (char *)(gx + (size_t)b_ * gxsample);
+        const unsigned sp0 = 4u * ((unsigned)((dz * d.H + h) * d.W + w0 + j) + (unsigned)(4 * g) * V);
+#pragma unroll
+        for (int t = 0; t < CT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ch = t * 16 + 4 * g + r;
+                if (ch < d.Cin) {
+                    const unsigned xo = sp0 + 4u * (unsigned)(t * 16 + r) * V;
+#pragma unroll
+                    for (int c = 0; c < CPW; ++c) *(float *)(xb + xo + 64u * c) = acc[c][t][r];
+                }
             }
     }
 }
@@ -677,6 +930,34 @@ extern "C" int wm_conv3d_fwd_f32(const float *x, const float *w, const float *b,
     const int ot = (Cout + 15) / 16;
     if (Ntot >= 16 * WIDE_TILES * 2 * wm_num_cus()) {          // enough tiles for two waves of blocks
         const int wblocks = (Ntot + 16 * WIDE_TILES - 1) / (16 * WIDE_TILES);
+        const int otk = ot == 3 ? 4 : ot;
+        const size_t lds = rows_lds_bytes(K, otk);
+        // 32-bit byte offsets inside one sample of x and of y
+        if (lds <= RESIDENT_LDS && d.OW >= ROWS_SEG && (long long)Cin * D * H * W < (1ll << 30) &&
+            (long long)Cout * d.OD * d.OH * d.OW < (1ll << 30)) {
+            // persistent: exactly the workgroups that are resident at once (registers and LDS
+            // decide; a grid above that runs its surplus as a second, mostly empty round)
+            const void *kfn = otk == 1   ? (const void *)conv3d_fwd_rows_kernel<1>
+                              : otk == 2 ? (const void *)conv3d_fwd_rows_kernel<2>
+                                         : (const void *)conv3d_fwd_rows_kernel<4>;
+            int occ = 0;
+            WM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, BLOCK, lds));
+            WM_REQUIRE(occ > 0, WM_ERR_HIP, "conv3d_fwd_rows_kernel does not fit on a CU");
+            const int units = B * d.OD * d.OH * ((d.OW + ROWS_SEG - 1) / ROWS_SEG);
+            int grid = wm_num_cus() * occ & ~7;
+            if (grid > (units + WAVES - 1) / WAVES) grid = ((units + WAVES - 1) / WAVES + 7) & ~7;
+            if (otk == 1)
+                hipLaunchKernelGGL(conv3d_fwd_rows_kernel<1>, dim3(grid), dim3(BLOCK), lds, st, x, w,
+                                   b, y, d, K, relu);
+            else if (otk == 2)
+                hipLaunchKernelGGL(conv3d_fwd_rows_kernel<2>, dim3(grid), dim3(BLOCK), lds, st, x, w,
+                                   b, y, d, K, relu);
+            else
+                hipLaunchKernelGGL(conv3d_fwd_rows_kernel<4>, dim3(grid), dim3(BLOCK), lds, st, x, w,
+                                   b, y, d, K, relu);
+            WM_LAUNCH_CHECK("conv3d_fwd_rows_kernel");
+            return WM_OK;
+        }
         if (ot == 1)
             hipLaunchKernelGGL(conv3d_fwd_wide_kernel<1>, dim3(wblocks), dim3(BLOCK), 0, st, x, w, b,
                                y, d, K, Ntot, relu);
@@ -717,6 +998,31 @@ extern "C" int wm_conv3d_bwd_data_f32(const float *gy, const float *w, float *gx
     const int ct = (Cin + 15) / 16;
     if (Mtot >= 16 * WIDE_TILES * 2 * wm_num_cus()) {
         const int wblocks = (Mtot + 16 * WIDE_TILES - 1) / (16 * WIDE_TILES);
+        const int ctk = ct == 3 ? 4 : ct;
+        const size_t lds = rows_lds_bytes(K2, ctk) + (size_t)rows_steps(K2) * 4 * sizeof(int);
+        if (lds <= RESIDENT_LDS && W >= ROWS_SEG && (long long)Cin * D * H * W < (1ll << 30) &&
+            (long long)Cout * d.OD * d.OH * d.OW < (1ll << 30)) {
+            const void *kfn = ctk == 1   ? (const void *)conv3d_bwd_data_rows_kernel<1>
+                              : ctk == 2 ? (const void *)conv3d_bwd_data_rows_kernel<2>
+                                         : (const void *)conv3d_bwd_data_rows_kernel<4>;
+            int occ = 0;
+            WM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, BLOCK, lds));
+            WM_REQUIRE(occ > 0, WM_ERR_HIP, "conv3d_bwd_data_rows_kernel does not fit on a CU");
+            const int units = B * D * H * ((W + ROWS_SEG - 1) / ROWS_SEG);
+            int grid = wm_num_cus() * occ & ~7;
+            if (grid > (units + WAVES - 1) / WAVES) grid = ((units + WAVES - 1) / WAVES + 7) & ~7;
+            if (ctk == 1)
+                hipLaunchKernelGGL(conv3d_bwd_data_rows_kernel<1>, dim3(grid), dim3(BLOCK), lds, st,
+                                   gy, w, gx, d, K2);
+            else if (ctk == 2)
+                hipLaunchKernelGGL(conv3d_bwd_data_rows_kernel<2>, dim3(grid), dim3(BLOCK), lds, st,
+                                   gy, w, gx, d, K2);
+            else
+                hipLaunchKernelGGL(conv3d_bwd_data_rows_kernel<4>, dim3(grid), dim3(BLOCK), lds, st,
+                                   gy, w, gx, d, K2);
+            WM_LAUNCH_CHECK("conv3d_bwd_data_rows_kernel");
+            return WM_OK;
+        }
         if (ct == 1)
             hipLaunchKernelGGL(conv3d_bwd_data_wide_kernel<1>, dim3(wblocks), dim3(BLOCK), 0, st, gy,
                                w, gx, d, K2, Mtot);
