@@ -815,6 +815,193 @@ __global__ __launch_bounds__(BLOCK) void conv3d_bwd_wb_wide_kernel(const float *
     }
 }
 
+// ------------------------------------------------------------------------------ backward w, b, rows
+// Weight/bias gradient of the large grids with both operands staged in LDS.  In the wide kernel
+// above every B operand is a 16-tap x 4-position gather from global memory (sixteen scattered
+// 16-byte pieces per wave instruction, each x element fetched kH*kW times per workgroup); here a
+// workgroup's unit is 64 consecutive outputs of one output row, whose input window
+// (Cin*kD*kH rows of 68 floats: 64 + halo) and gy rows (Cout rows of 64 floats) are copied once
+// into LDS by 16-byte LDS-direct loads (global_load_lds_dwordx4: the LDS image is filled
+// linearly, one KiB per wave instruction, and each lane's SOURCE address picks the piece of the
+// row that belongs there, pitch padding included), and the MFMA operands are LDS reads at
+// immediate offsets of per-lane bases fixed for the whole kernel.  (Row-by-row dword copies of
+// the same tile were instruction-bound: 224 wave instructions per unit, 1.26 ms of a 2.5 ms
+// pass; this fill issues 36.)  Pitches (72 and 68 words) keep the 16 taps x 4 positions of a B
+// read and the 16 channels x 4 positions of an A read on distinct banks.  Accumulators stay in
+// registers across units and go to the workgroup's float64 slab every WBR_FLUSH units (1024
+// outputs), as in the wide kernel.
+constexpr int WBR_SEG = 64;        // outputs per unit
+constexpr int WBR_XP = 72;         // x row pitch in LDS (words): 18 pieces of 16 bytes, = 8 mod 64
+constexpr int WBR_XW = 68;         // x columns fetched per row (17 pieces): kW - 1 <= 4
+constexpr int WBR_GP = 68;         // gy row pitch (words): 17 pieces, = 4 mod 64
+constexpr int WBR_FLUSH = 16;
+constexpr int WBR_MAXX = 9;        // x pieces / 256 per thread  (Cin*kD*kH <= 128 rows)
+constexpr int WBR_MAXG = 5;        // gy pieces / 256            (Cout <= 64)
+
+__host__ __device__ inline size_t wbr_lds_bytes(int rows, int ot)
+{
+    return ((size_t)rows * WBR_XP + (size_t)ot * 16 * WBR_GP + 2 * WBR_XP) * sizeof(float);
+}
+
+#define WM_GLDS16(src, dst)                                                                    \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src),    \
+                                     (__attribute__((address_space(3))) void *)(dst), 16, 0, 0)
+
+template <int OT, int KTW>
+__global__ __launch_bounds__(BLOCK) void conv3d_bwd_wb_rows_kernel(const float *__restrict__ x,
+                                                                   const float *__restrict__ gy,
+                                                                   double *__restrict__ partial,
+                                                                   Dims3 d, int K, int ktiles)
+{
+    extern __shared__ __align__(16) float smem[];
+    const int rows = d.Cin * d.kD * d.kH;
+    // [rows][WBR_XP] x | [OT*16][WBR_GP] gy | [WBR_XP] ones | [WBR_XP] zeros
+    const int goff = rows * WBR_XP, ooff = goff + OT * 16 * WBR_GP, zoff = ooff + WBR_XP;
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int S = d.OD * d.OH * d.OW;
+    // the slab is [Cout][K + 1] float64: column K is the bias gradient
+    char *slab = (char *)(partial + (size_t)blockIdx.x * d.Cout * (K + 1));
+
+    for (int e = tid; e < OT * 16 * WBR_GP; e += BLOCK) smem[goff + e] = 0.0f;   // rows >= Cout stay zero
+    for (int e = tid; e < WBR_XP; e += BLOCK) { smem[ooff + e] = 1.0f; smem[zoff + e] = 0.0f; }
+
+    // this lane's B-operand base (LDS word) of tap tile q: tap k = (wave + WAVES q) 16 + j
+    int koff[KTW];
+#pragma unroll
+    for (int q = 0; q < KTW; ++q) {
+        const int k = (wave + WAVES * q) * 16 + j;
+        int o_ = zoff;
+        if (k < K) {
+            const int kw = k % d.kW, r_ = k / d.kW;      // r_ = (c*kD + kd)*kH + kh: the LDS row
+            o_ = r_ * WBR_XP + kw;
+        } else if (k == K) {
+            o_ = ooff;
+        }
+        koff[q] = o_ + g;
+    }
+    const int abase = goff + j * WBR_GP + g;
+
+    // 16-byte pieces of the LDS image this thread fills, fixed for the kernel: piece P = tid +
+    // 256 i of the x part is row P / 18, columns 4 (P % 18).. (the 18th piece of a row is pitch
+    // padding and repeats the 17th); of the gy part row P / 17, columns 4 (P % 17).. (the 17th is
+    // padding).  Element offsets from the unit's first column; -1 = nothing to fill.
+    const int nxs = (rows * 18 + BLOCK - 1) / BLOCK, ngs = (d.Cout * 17 + BLOCK - 1) / BLOCK;
+    int xsrc_off[WBR_MAXX], gsrc_off[WBR_MAXG];
+#pragma unroll
+    for (int i = 0; i < WBR_MAXX; ++i) {
+        const int P = tid + BLOCK * i, r_ = P / 18, pc = P - 18 * r_;
+        int o_ = -1;
+        if (r_ < rows) {
+            const int kh = r_ % d.kH, t_ = r_ / d.kH, kd = t_ % d.kD, c = t_ / d.kD;
+            o_ = ((c * d.D + kd) * d.H + kh) * d.W + 4 * min(pc, 16);
+        }
+        xsrc_off[i] = o_;
+    }
+#pragma unroll
+    for (int i = 0; i < WBR_MAXG; ++i) {
+        const int P = tid + BLOCK * i, o = P / 17, pc = P - 17 * o;
+        gsrc_off[i] = o < d.Cout ? o * S + 4 * min(pc, 15) : -1;
+    }
+
+    // byte offset in the slab of this lane's entry (o = 4 g, tap k_b) of tile q
+    unsigned voff[KTW];
+#pragma unroll
+    for (int q = 0; q < KTW; ++q)
+        voff[q] = 8u * (unsigned)((wave + WAVES * q) * 16 + j + 4 * g * (K + 1));
+
+    const int segs = (d.OW + WBR_SEG - 1) / WBR_SEG;
+    const int units = d.B * d.OD * d.OH * segs;
+    const int upx = (units + 7) >> 3;
+    const int xcd = blockIdx.x & 7, nslot = gridDim.x >> 3;
+    const int uend = min(units, (xcd + 1) * upx);
+    const size_t xsample = (size_t)d.Cin * d.D * d.H * d.W, gsample = (size_t)d.Cout * S;
+    for (int ubase = xcd * upx + ((int)blockIdx.x >> 3); ubase < uend; ubase += nslot * WBR_FLUSH) {
+    f32x4 acc[KTW][OT];
+#pragma unroll
+    for (int q = 0; q < KTW; ++q)
+#pragma unroll
+        for (int t = 0; t < OT; ++t) acc[q][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int ustop = min(uend, ubase + nslot * WBR_FLUSH);
+    for (int unit = ubase; unit < ustop; unit += nslot) {
+        const int row = unit / segs, seg = unit - row * segs;
+        // the last segment of a row is moved left to end at the row's end (the outputs it then
+        // shares with the segment before are masked out of gy), and its 68-column input window a
+        // little further so that it stays inside the row: B reads then start delta words in
+        const int ow0 = min(seg * WBR_SEG, d.OW - WBR_SEG);
+        const int xs0 = min(ow0, d.W - WBR_XW), delta = ow0 - xs0;
+        const int oh = row % d.OH, q_ = row / d.OH, od = q_ % d.OD, b_ = q_ / d.OD;
+        const float *xsrc = x + (size_t)b_ * xsample + (size_t)((od * d.H + oh) * d.W + xs0);
+        const float *gsrc = gy + (size_t)b_ * gsample + (size_t)((od * d.OH + oh) * d.OW + ow0);
+        __syncthreads();                                   // every wave is past its reads of the tile
+#pragma unroll
+        for (int i = 0; i < WBR_MAXX; ++i)
+            if (i < nxs) {
+                if (xsrc_off[i] >= 0) WM_GLDS16(xsrc + xsrc_off[i], smem + (BLOCK * i + 64 * wave) * 4);
+            }
+        if (ow0 == seg * WBR_SEG) {
+#pragma unroll
+            for (int i = 0; i < WBR_MAXG; ++i)
+                if (i < ngs) {
+                    if (gsrc_off[i] >= 0)
+                        WM_GLDS16(gsrc + gsrc_off[i], smem + goff + (BLOCK * i + 64 * wave) * 4);
+                }
+        } else {
+            for (int e = tid; e < d.Cout * WBR_SEG; e += BLOCK) {
+                const int o = e >> 6, n = e & 63;
+                const float v = gsrc[(size_t)o * S + n];
+                smem[goff + o * WBR_GP + n] = ow0 + n >= seg * WBR_SEG ? v : 0.0f;
+            }
+        }
+        __syncthreads();                                   // vmcnt(0) + barrier: the tile has landed
+        // operands of step s+1 are read while the MFMAs of step s run; the barriers keep hipcc
+        // from hoisting all 16 steps' LDS reads to the top (it did: 244 VGPRs)
+#define WBR_OPS(a_, b_, s_)                                                                  \
+    _Pragma("unroll") for (int t = 0; t < OT; ++t) a_[t] = smem[abase + t * 16 * WBR_GP + 4 * (s_)]; \
+    _Pragma("unroll") for (int q = 0; q < KTW; ++q) b_[q] = smem[kofd[q] + 4 * (s_)];
+#define WBR_MMA(a_, b_)                                                                      \
+    _Pragma("unroll") for (int q = 0; q < KTW; ++q)                                          \
+        _Pragma("unroll") for (int t = 0; t < OT; ++t) acc[q][t] = mma(a_[t], b_[q], acc[q][t]);
+        float a0[OT], b0[KTW], a1[OT], b1[KTW];
+        int kofd[KTW];
+#pragma unroll
+        for (int q = 0; q < KTW; ++q) kofd[q] = koff[q] + delta;
+        WBR_OPS(a0, b0, 0)
+#pragma unroll
+        for (int s_ = 0; s_ < WBR_SEG / 4; s_ += 2) {
+            WBR_OPS(a1, b1, s_ + 1)
+            __builtin_amdgcn_sched_barrier(0);
+            WBR_MMA(a0, b0)
+            __builtin_amdgcn_sched_barrier(0);
+            if (s_ + 2 < WBR_SEG / 4) { WBR_OPS(a0, b0, s_ + 2) }
+            __builtin_amdgcn_sched_barrier(0);
+            WBR_MMA(a1, b1)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef WBR_OPS
+#undef WBR_MMA
+    }
+    // WBR_FLUSH units (1024 outputs) of fp32 accumulation go to the float64 slab
+#pragma unroll
+    for (int q = 0; q < KTW; ++q) {
+        const bool kin = (wave + WAVES * q) * 16 + j <= K;
+        // opaque copy: otherwise hipcc hoists all KTW*OT*4 64-bit entry addresses out of the
+        // unit loops and keeps them in VGPRs (80 registers for 32 -> 32 channels 3x3)
+        unsigned vo = voff[q];
+        asm volatile("" : "+v"(vo));
+#pragma unroll
+        for (int t = 0; t < OT; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                char *sb = slab + (size_t)(t * 16 + r) * (K + 1) * sizeof(double);   // wave-uniform
+                if (kin && t * 16 + 4 * g + r < d.Cout) *(double *)(sb + vo) += (double)acc[q][t][r];
+            }
+            __builtin_amdgcn_sched_barrier(0);             // four read-modify-writes in flight, not all
+        }
+    }
+    }
+}
+
 __global__ __launch_bounds__(64) void conv3d_reduce_kernel(const double *__restrict__ partial,
                                                            int nparts, int nent, int nw,
                                                            float *__restrict__ gw,
@@ -826,6 +1013,32 @@ __global__ __launch_bounds__(64) void conv3d_reduce_kernel(const double *__restr
     for (int p = 0; p < nparts; ++p) s += partial[(size_t)p * nent + e];
     if (e < nw) gw[e] = (float)s;
     else if (gb) gb[e - nw] = (float)s;
+}
+
+// the same sum for many slabs (one per persistent workgroup): 64 entries x 16 slab groups per
+// workgroup, group partials combined through LDS in a fixed order
+__global__ __launch_bounds__(1024) void conv3d_reduce_slabs_kernel(const double *__restrict__ partial,
+                                                                   int nparts, int Cout, int K,
+                                                                   float *__restrict__ gw,
+                                                                   float *__restrict__ gb)
+{
+    __shared__ double part[16][64];
+    const int le = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int nent = Cout * (K + 1);                    // slab = [Cout][K + 1], column K = bias
+    const int e = blockIdx.x * 64 + le;
+    double s = 0.0;
+    if (e < nent)
+        for (int p = grp; p < nparts; p += 16) s += partial[(size_t)p * nent + e];
+    part[grp][le] = s;
+    __syncthreads();
+    if (grp == 0 && e < nent) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += part[q][le];
+        const int o = e / (K + 1), k = e - o * (K + 1);
+        if (k < K) gw[(size_t)o * K + k] = (float)t;
+        else if (gb) gb[o] = (float)t;
+    }
 }
 
 // ------------------------------------------------------------------------------ max pool
@@ -891,6 +1104,50 @@ bool wb_wide_shape(long long Ntot, int K)
 {
     const int cus = wm_num_cus();
     return cus > 0 && Ntot >= 4096ll * cus && (K + 1 + 15) / 16 <= 8 * WAVES;
+}
+
+// The LDS-staged row kernel: grid (a multiple of 8, one float64 slab per workgroup), LDS bytes and
+// kernel for a shape, or false when the shape takes another path.
+typedef void (*wb_rows_fn)(const float *, const float *, double *, Dims3, int, int);
+wb_rows_fn wb_rows_kernel(int otiles, int ktw)
+{
+#define WBR_K(OT_)                                                                \
+    switch (ktw) {                                                                \
+    case 1: return conv3d_bwd_wb_rows_kernel<OT_, 1>;                             \
+    case 2: return conv3d_bwd_wb_rows_kernel<OT_, 2>;                             \
+    case 3: return conv3d_bwd_wb_rows_kernel<OT_, 3>;                             \
+    case 4: return conv3d_bwd_wb_rows_kernel<OT_, 4>;                             \
+    case 5: return conv3d_bwd_wb_rows_kernel<OT_, 5>;                             \
+    case 6: return conv3d_bwd_wb_rows_kernel<OT_, 6>;                             \
+    case 7: return conv3d_bwd_wb_rows_kernel<OT_, 7>;                             \
+    default: return conv3d_bwd_wb_rows_kernel<OT_, 8>;                            \
+    }
+    if (otiles == 1) { WBR_K(1) }
+    if (otiles == 2) { WBR_K(2) }
+    WBR_K(4)
+#undef WBR_K
+}
+
+bool wb_rows_plan(int B, int Cin, int D, int H, int W, int Cout, int kD, int kH, int kW, int *grid,
+                  size_t *lds)
+{
+    const int OD = D - kD + 1, OH = H - kH + 1, OW = W - kW + 1;
+    const long long Ntot = (long long)B * OD * OH * OW;
+    const int K = Cin * kD * kH * kW;
+    if (!wb_wide_shape(Ntot, K) || kW - 1 > WBR_XW - WBR_SEG || W < WBR_XW || OW < WBR_SEG) return false;
+    const int otiles = (Cout + 15) / 16, ktiles = (K + 1 + 15) / 16;
+    const size_t bytes = wbr_lds_bytes(Cin * kD * kH, otiles == 3 ? 4 : otiles);
+    if (bytes > RESIDENT_LDS || Cin * kD * kH * 18 > BLOCK * WBR_MAXX) return false;
+    const void *kfn = (const void *)wb_rows_kernel(otiles, (ktiles + WAVES - 1) / WAVES);
+    if (bytes > 64 * 1024 &&
+        hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
+        return false;
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, BLOCK, bytes) != hipSuccess || occ <= 0)
+        return false;
+    *grid = wm_num_cus() * occ & ~7;
+    *lds = bytes;
+    return *grid > 0;
 }
 
 int fill_dims(Dims3 *d, int B, int Cin, int D, int H, int W, int Cout, int kD, int kH, int kW)
@@ -1059,6 +1316,9 @@ extern "C" size_t wm_conv3d_bwd_wb_workspace_bytes(int B, int Cin, int D, int H,
     size_t splits = (size_t)((Ntot + NCHUNK - 1) / NCHUNK);
     const size_t nent = (size_t)Cout * Cin * kD * kH * kW + Cout;
     if (wb_wide_shape(Ntot, Cin * kD * kH * kW)) splits = (size_t)wm_num_cus() * WB_WIDE_BPC;   // one slab per workgroup
+    int rgrid = 0;
+    size_t rlds = 0;
+    if (wb_rows_plan(B, Cin, D, H, W, Cout, kD, kH, kW, &rgrid, &rlds)) splits = (size_t)rgrid;
     return wm_align_up(splits * nent * sizeof(double), 256);
 }
 
@@ -1082,6 +1342,18 @@ extern "C" int wm_conv3d_bwd_wb_f32(const float *x, const float *gy, float *gw, 
     const int tiles = ktiles * otiles;
     const int nw = Cout * K, nent = nw + Cout;
     hipStream_t st = (hipStream_t)stream;
+    int rgrid = 0;
+    size_t rlds = 0;
+    if (wb_rows_plan(B, Cin, D, H, W, Cout, kD, kH, kW, &rgrid, &rlds)) {
+        WM_HIP(hipMemsetAsync(workspace, 0, (size_t)rgrid * nent * sizeof(double), st));
+        hipLaunchKernelGGL(wb_rows_kernel(otiles, (ktiles + WAVES - 1) / WAVES), dim3(rgrid),
+                           dim3(BLOCK), rlds, st, x, gy, (double *)workspace, d, K, ktiles);
+        WM_LAUNCH_CHECK("conv3d_bwd_wb_rows_kernel");
+        hipLaunchKernelGGL(conv3d_reduce_slabs_kernel, dim3((nent + 63) / 64), dim3(1024), 0, st,
+                           (const double *)workspace, rgrid, Cout, K, gw, gb);
+        WM_LAUNCH_CHECK("conv3d_reduce_slabs_kernel");
+        return WM_OK;
+    }
     if (wb_wide_shape(Ntot, K)) {
         const int grid = wm_num_cus() * WB_WIDE_BPC;
         WM_HIP(hipMemsetAsync(workspace, 0, (size_t)grid * nent * sizeof(double), st));
