@@ -412,8 +412,8 @@ def run_conv32(steps, warmup, rank, world, cpu_base, N=8, C=32, H=721, W=1440):
                                    f"({N},{C},{H},{W}) per GPU"},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF,
                          "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF, "traffic": None,
-                         "kernel": "conv3d_fwd_wide_kernel + conv3d_bwd_data_wide_kernel + "
-                                   "conv3d_bwd_wb_wide_kernel",
+                         "kernel": "conv3d_fwd_rows_kernel + conv3d_bwd_data_rows_kernel + "
+                                   "conv3d_bwd_wb_rows_kernel",
                          "algorithmic_flops_per_point_per_pass": 2 * C * C * 9,
                          "TFLOPs": {k: flops_pass / (v * 1e-3) / 1e12 for k, v in ms.items()}}}
 
