@@ -57,6 +57,15 @@ CONV3D_CASES = [
 ]
 
 
+# large 3-D grids: the persistent row kernels with a real depth axis (kD > 1, border rows in depth
+# and height, rows that do not divide into 64-output segments, ragged channel tiles).  Checked
+# against the oracle only (no committed vectors).
+CONV3D_LARGE_CASES = [
+    ("rows_fwd_bwd", 1, 8, (9, 70, 330), 24, (2, 3, 3), 36, 1),     # 185 k outputs
+    ("rows_all", 2, 8, (20, 100, 330), 16, (2, 3, 3), 37, 1),       # 1.2 M outputs: also the LDS-staged weight gradient
+]
+
+
 def conv3d_inputs(case):
     name, B, Cin, dhw, Cout, k, seed, _ = case
     x = synth.uniform(seed * 10 + 1, (B, Cin) + dhw)

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from cases import CONV3D_CASES, conv3d_inputs
+from cases import CONV3D_CASES, CONV3D_LARGE_CASES, conv3d_inputs
 from conftest import relinf
 from weather_model_amd import ops, synth
 
@@ -55,6 +55,22 @@ def test_conv3d_forward_backward_vs_oracle(case, ocpu, g3):
     assert relinf(y0, ocpu.conv3d_fwd(x, w, None)) < TOL
     yr = ops.conv3d_forward(xd, wd, bd, relu=True).cpu().numpy()
     np.testing.assert_array_equal(yr, np.maximum(y, 0.0))
+
+
+@pytest.mark.parametrize("case", CONV3D_LARGE_CASES, ids=[c[0] for c in CONV3D_LARGE_CASES])
+def test_conv3d_large_grids_vs_oracle(case, ocpu):
+    """The persistent row kernels (conv3d_*_rows_kernel) on grids with a depth axis."""
+    x, w, b, gy = conv3d_inputs(case)
+    xd, wd, bd, gyd = _dev(x, w, b, gy)
+    assert relinf(ops.conv3d_forward(xd, wd, bd).cpu().numpy(), ocpu.conv3d_fwd(x, w, b)) < TOL
+    assert relinf(ops.conv3d_backward_data(gyd, wd, x.shape).cpu().numpy(),
+                  ocpu.conv3d_bwd_data(gy, w, x.shape)) < TOL
+    gw, gb = ops.conv3d_backward_wb(xd, gyd, w.shape)
+    ow, ob = ocpu.conv3d_bwd_wb(x, gy, w.shape)
+    assert relinf(gw.cpu().numpy(), ow) < TOL
+    assert relinf(gb.cpu().numpy(), ob) < TOL
+    again = ops.conv3d_backward_wb(xd, gyd, w.shape)
+    assert torch.equal(gw, again[0]) and torch.equal(gb, again[1])      # fixed-order sums
 
 
 def test_conv3d_bwd_wb_is_bitwise_reproducible():
