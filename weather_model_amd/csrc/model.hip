@@ -96,23 +96,41 @@ __device__ __forceinline__ void put_tile(float *dst, int stride, int row0, int c
 // forward conv layer: Hout[o][n] = relu(b[o] + as[o] s[n] + ae[o] e[n] + sum_c Wm[o][c] Hin[c][n])
 // K = Cin (0 for conv1), O = Cout; weight element (o,c) sits at wbase[(o*K + c)*3 + 1].
 // Packed operands (LDS, wp): per o-tile 1 + K/4 operands; operand 0 = [b, as, ae, 0] by lane group.
+// A layer has at most 2*WAVES units, each one dependent chain of MFMAs on a single accumulator; a
+// wave that owns two units runs the two chains interleaved (the phases are latency-bound: SQ
+// counters show the MFMA pipe 41 % busy with the waves waiting 56 % of the time).
 template <int K, int O>
 __device__ __forceinline__ void conv_fwd_layer(float *lds, int wp, int hin, int hout, int wave,
                                                int lane, int i, int g)
 {
     constexpr int UNITS = (O / 16) * 6;
     constexpr int STEPS = K / 4 + 1;
-    for (int u = wave; u < UNITS; u += WAVES) {
-        const int ot = u / 6, o0 = ot * 16, c0 = (u % 6) * 16;
-        const float *a = lds + wp + ot * STEPS * 64 + lane;
-        // rank-1 terms and bias as one MFMA step: A = [b, as, ae, 0], B = [1, s, e, 0]
-        const float b0 = lds[L_EE + g * NP + c0 + i];   // EE rows 0..3 = 1, s, e, 0
-        f32x4 acc = mma(a[0], b0, (f32x4){0.f, 0.f, 0.f, 0.f});
+    static_assert(UNITS <= 2 * WAVES, "two units per wave at most");
+    if (wave >= UNITS) return;
+    const int u0 = wave, u1 = wave + WAVES;
+    const int o0 = (u0 / 6) * 16, c0 = (u0 % 6) * 16;
+    const float *a0 = lds + wp + (u0 / 6) * STEPS * 64 + lane;
+    // rank-1 terms and bias as one MFMA step: A = [b, as, ae, 0], B = [1, s, e, 0]
+    const float *ee = lds + L_EE + g * NP + i;            // EE rows 0..3 = 1, s, e, 0
+    const float *hb = lds + hin + (K / 4) * g * NP + i;
+    if (u1 < UNITS) {
+        const int o1 = (u1 / 6) * 16, c1 = (u1 % 6) * 16;
+        const float *a1 = lds + wp + (u1 / 6) * STEPS * 64 + lane;
+        f32x4 acc0 = mma(a0[0], ee[c0], (f32x4){0.f, 0.f, 0.f, 0.f});
+        f32x4 acc1 = mma(a1[0], ee[c1], (f32x4){0.f, 0.f, 0.f, 0.f});
 #pragma unroll
         for (int t = 0; t < K / 4; ++t) {
-            const int k = t + (K / 4) * g;
-            acc = mma(a[(t + 1) * 64], lds[hin + k * NP + c0 + i], acc);
+            acc0 = mma(a0[(t + 1) * 64], hb[t * NP + c0], acc0);
+            acc1 = mma(a1[(t + 1) * 64], hb[t * NP + c1], acc1);
         }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { acc0[r] = fmaxf(acc0[r], 0.0f); acc1[r] = fmaxf(acc1[r], 0.0f); }
+        put_tile(lds + hout, NP, o0, c0, acc0, i, g);
+        put_tile(lds + hout, NP, o1, c1, acc1, i, g);
+    } else {
+        f32x4 acc = mma(a0[0], ee[c0], (f32x4){0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+        for (int t = 0; t < K / 4; ++t) acc = mma(a0[(t + 1) * 64], hb[t * NP + c0], acc);
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] = fmaxf(acc[r], 0.0f);
         put_tile(lds + hout, NP, o0, c0, acc, i, g);
@@ -125,15 +143,34 @@ __device__ __forceinline__ void conv_bwd_data_layer(float *lds, int wp, int zout
                                                     int wave, int lane, int i, int g)
 {
     constexpr int UNITS = (K / 16) * 6;
-    for (int u = wave; u < UNITS; u += WAVES) {
-        const int ct = u / 6, c0 = ct * 16, n0 = (u % 6) * 16;
-        const float *a = lds + wp + ct * (O / 4) * 64 + lane;
-        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    static_assert(UNITS <= 2 * WAVES, "two units per wave at most");
+    if (wave >= UNITS) return;
+    const int u0 = wave, u1 = wave + WAVES;
+    const int c0 = (u0 / 6) * 16, n0 = (u0 % 6) * 16;
+    const float *a0 = lds + wp + (u0 / 6) * (O / 4) * 64 + lane;
+    const float *zb = lds + zout + (O / 4) * g * NP + i;
+    if (u1 < UNITS) {
+        const int c1 = (u1 / 6) * 16, n1 = (u1 % 6) * 16;
+        const float *a1 = lds + wp + (u1 / 6) * (O / 4) * 64 + lane;
+        f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < O / 4; ++t) {
-            const int o = t + (O / 4) * g;
-            acc = mma(a[t * 64], lds[zout + o * NP + n0 + i], acc);
+            acc0 = mma(a0[t * 64], zb[t * NP + n0], acc0);
+            acc1 = mma(a1[t * 64], zb[t * NP + n1], acc1);
         }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float h0 = lds[hin + (c0 + 4 * g + r) * NP + n0 + i];
+            const float h1 = lds[hin + (c1 + 4 * g + r) * NP + n1 + i];
+            acc0[r] = h0 > 0.0f ? acc0[r] : 0.0f;
+            acc1[r] = h1 > 0.0f ? acc1[r] : 0.0f;
+        }
+        put_tile(lds + zin, NP, c0, n0, acc0, i, g);
+        put_tile(lds + zin, NP, c1, n1, acc1, i, g);
+    } else {
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < O / 4; ++t) acc = mma(a0[t * 64], zb[t * NP + n0], acc);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float hv = lds[hin + (c0 + 4 * g + r) * NP + n0 + i];
@@ -462,11 +499,34 @@ __global__ __launch_bounds__(THREADS) void model_kernel(
         conv_bwd_data_layer<16, 32>(lds, W_C2B, L_Z2, L_H1, L_Z1, wave, lane, i, g);
         __syncthreads();
         // ---- weight gradients: every tile owned by one wave, accumulated in registers
+        // slots in pairs: two tiles with the same step count run as two interleaved chains
 #pragma unroll
-        for (int s = 0; s < SLOTS; ++s) {
-            const int id = grad_tile_of(s, wave);
-            if (id >= 0) {
-                const GradTile t = grad_tile(id);
+        for (int s = 0; s < SLOTS; s += 2) {
+            const int id0 = grad_tile_of(s, wave);
+            const int id1 = s + 1 < SLOTS ? grad_tile_of(s + 1, wave) : -1;
+            if (id0 >= 0 && id1 >= 0) {
+                const GradTile t0 = grad_tile(id0), t1 = grad_tile(id1);
+                const float *ap0 = lds + t0.a_off + i * t0.a_stride + t0.ka0 + g;
+                const float *bp0 = lds + t0.b_off + i * t0.b_stride + t0.kb0 + g;
+                const float *ap1 = lds + t1.a_off + i * t1.a_stride + t1.ka0 + g;
+                const float *bp1 = lds + t1.b_off + i * t1.b_stride + t1.kb0 + g;
+                f32x4 acc0 = gacc[s], acc1 = gacc[s + 1 < SLOTS ? s + 1 : s];
+                if (t0.steps == t1.steps) {
+#pragma unroll 4
+                    for (int k = 0; k < t0.steps; ++k) {
+                        acc0 = mma(ap0[4 * k], bp0[4 * k], acc0);
+                        acc1 = mma(ap1[4 * k], bp1[4 * k], acc1);
+                    }
+                } else {
+#pragma unroll 4
+                    for (int k = 0; k < t0.steps; ++k) acc0 = mma(ap0[4 * k], bp0[4 * k], acc0);
+#pragma unroll 4
+                    for (int k = 0; k < t1.steps; ++k) acc1 = mma(ap1[4 * k], bp1[4 * k], acc1);
+                }
+                gacc[s] = acc0;
+                if (s + 1 < SLOTS) gacc[s + 1] = acc1;
+            } else if (id0 >= 0) {
+                const GradTile t = grad_tile(id0);
                 const float *ap = lds + t.a_off + i * t.a_stride + t.ka0 + g;
                 const float *bp = lds + t.b_off + i * t.b_stride + t.kb0 + g;
                 f32x4 acc = gacc[s];
