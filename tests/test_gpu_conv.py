@@ -57,6 +57,42 @@ def test_conv_full_grid_721x1440(conv_golden):
     assert relinf(gx[:, :, -8:, -8:], g["grid721/gx_br"]) < TOL
 
 
+def test_conv32_full_size_adjoint_identities():
+    """BASELINE config 4b at its full size, Conv2d(32 -> 32, 3x3) on (8,32,721,1440): the three
+    passes checked against each other through the identities every linear map and its adjoints
+    satisfy (no oracle needed at 1.2 TFLOP):  <A x, g> = <x, A^T g> = <w, dW(x, g)>  with A the
+    bias-free convolution, and  db = sum g.  Dot products in float64 on the device."""
+    import torch
+    from weather_model_amd import ops
+    N, C, H, W = 8, 32, 721, 1440
+    x = ops.synth_uniform((N, C, H, W), seed=91)
+    w = ops.synth_uniform((C, C, 3, 3), seed=92, lo=-1.0 / 17, hi=1.0 / 17)
+    b = ops.synth_uniform((C,), seed=93, lo=-1.0, hi=1.0)
+    g = ops.synth_uniform((N, C, H - 2, W - 2), seed=94, lo=-1.0, hi=1.0)
+
+    def dot(a, c):
+        return float((a.double().flatten() * c.double().flatten()).sum())
+
+    y0 = ops.conv2d_forward(x, w, None)
+    lhs = dot(y0, g)
+    y = ops.conv2d_forward(x, w, b)
+    # the bias enters once per output position
+    assert torch.allclose(y[:, :, 100, 200] - y0[:, :, 100, 200], b.expand(N, C), atol=1e-6)
+    del y, y0
+    gx = ops.conv2d_backward_data(g, w, x.shape)
+    mid = dot(x, gx)
+    del gx
+    gw, gb = ops.conv2d_backward_wb(x, g, w.shape)
+    rhs = dot(w, gw)
+    scale = float((x.double() ** 2).sum().sqrt() * (g.double() ** 2).sum().sqrt()) / 17
+    assert abs(lhs - mid) < 5e-8 * scale and abs(lhs - rhs) < 5e-8 * scale, (lhs, mid, rhs, scale)
+    gsum = g.double().sum((0, 2, 3))
+    assert float((gb.double() - gsum).abs().max()) < 1e-5 * float(g.double().abs().sum((0, 2, 3)).max())
+    # linearity of the weight gradient in gy (size-independent property)
+    gw2, gb2 = ops.conv2d_backward_wb(x, 2.0 * g, w.shape)
+    assert float((gw2 - 2.0 * gw).abs().max()) <= 2e-6 * float(gw.abs().max())
+
+
 @pytest.mark.parametrize("shape", [
     (1, 1, 3, 19, 1, 3, 3),       # a single output row, OW = 17 (stencil path, ragged strip)
     (5, 1, 40, 66, 1, 3, 3),      # ranges that cross image boundaries
