@@ -129,6 +129,9 @@ def run_gram(F, n_rows, steps, warmup, rank, world, cpu_base):
 
     def step(i, timed):
         plan.acc.zero_()
+        # the Gram pass is bracketed by HIP events on every other timed step (an event record
+        # costs a few microseconds on the stream)
+        timed = timed and (steps < 4 or i % 2 == 0)
         if timed:
             e = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             e[0].record()
@@ -214,22 +217,31 @@ def run_conv(steps, warmup, rank, world, cpu_base, N=64, H=721, W=1440):
     fwd_ev, bwd_ev = [], []
 
     def step(i, ev):
+        # An event record costs ~7 us on the stream (three per step made a 200 us step 220 us), so
+        # the kernels are bracketed on a quarter of the timed steps only: forward on steps
+        # 0, 4, 8.., backward on steps 2, 6, 10.. (every step for runs too short for that)
         k = i % nset
         st = torch.cuda.current_stream().cuda_stream
-        if ev:
-            e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-            e[0].record()
+        mod = 4 if steps >= 8 else (2 if steps >= 2 else 1)
+        ef = ev and i % mod == 0
+        eb = ev and i % mod == mod // 2
+        if ef:
+            f0, f1 = (torch.cuda.Event(enable_timing=True) for _ in range(2))
+            f0.record()
         _lib.check(L.wm_conv2d_fwd_f32(xs[k].data_ptr(), w.data_ptr(), b.data_ptr(),
                                        ys[k].data_ptr(), N, 1, H, W, 1, 3, 3, 0, st))
-        if ev:
-            e[1].record()
+        if ef:
+            f1.record()
+            fwd_ev.append((f0, f1))
+        if eb:
+            b0, b1 = (torch.cuda.Event(enable_timing=True) for _ in range(2))
+            b0.record()
         _lib.check(L.wm_conv2d_bwd_wb_f32(xs[k].data_ptr(), gys[k].data_ptr(), grads.data_ptr(),
                                           grads[9:].data_ptr(), ws.data_ptr(), ws.numel(),
                                           N, 1, H, W, 1, 3, 3, st))
-        if ev:
-            e[2].record()
-            fwd_ev.append((e[0], e[1]))
-            bwd_ev.append((e[1], e[2]))
+        if eb:
+            b1.record()
+            bwd_ev.append((b0, b1))
         if world > 1:
             dp.reduce_grads_(grads)              # DP weight-gradient exchange (10 floats)
 
