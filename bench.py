@@ -423,7 +423,11 @@ def run_conv32(steps, warmup, rank, world, cpu_base, N=8, C=32, H=721, W=1440):
             "config": {"workload": f"Conv2d({C}->{C}, 3x3) fwd + bwd(data, weight, bias) on "
                                    f"({N},{C},{H},{W}) per GPU"},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF,
-                         "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF, "traffic": None,
+                         "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF,
+                         "traffic": pmc_traffic(["conv3d_fwd_rows_kernel<2>",
+                                                 "conv3d_bwd_data_rows_kernel<2>",
+                                                 "conv3d_bwd_wb_rows_kernel<2, 5>"],
+                                                (N, C, H, W) == (8, 32, 721, 1440)),
                          "kernel": "conv3d_fwd_rows_kernel + conv3d_bwd_data_rows_kernel + "
                                    "conv3d_bwd_wb_rows_kernel",
                          "algorithmic_flops_per_point_per_pass": 2 * C * C * 9,
