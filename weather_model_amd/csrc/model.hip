@@ -85,6 +85,20 @@ __device__ __forceinline__ f32x4 mma(float a, float b, f32x4 c)
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// tanh(u) = 1 - 2 / (exp(2u) + 1) on the hardware exp2 / rcp: absolute error < 4e-7 (the libm
+// tanhf took 1 k of the 28.7 k cycles of a tile); saturates correctly at +-1
+__device__ __forceinline__ float fast_tanh(float u)
+{
+    return 1.0f - __fdividef(2.0f, __expf(2.0f * u) + 1.0f);
+}
+
+// Barrier between two phases that communicate through LDS only (no vmcnt(0) drain: loads whose
+// values are consumed later stay in flight across it).
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // write a 16x16 accumulator tile (row = 4g + r, col = i) into an LDS matrix
 __device__ __forceinline__ void put_tile(float *dst, int stride, int row0, int col0, f32x4 acc,
                                          int i, int g)
@@ -96,91 +110,61 @@ __device__ __forceinline__ void put_tile(float *dst, int stride, int row0, int c
 // forward conv layer: Hout[o][n] = relu(b[o] + as[o] s[n] + ae[o] e[n] + sum_c Wm[o][c] Hin[c][n])
 // K = Cin (0 for conv1), O = Cout; weight element (o,c) sits at wbase[(o*K + c)*3 + 1].
 // Packed operands (LDS, wp): per o-tile 1 + K/4 operands; operand 0 = [b, as, ae, 0] by lane group.
-// A layer has at most 2*WAVES units, each one dependent chain of MFMAs on a single accumulator; a
-// wave that owns two units runs the two chains interleaved (the phases are latency-bound: SQ
-// counters show the MFMA pipe 41 % busy with the waves waiting 56 % of the time).
-template <int K, int O>
-__device__ __forceinline__ void conv_fwd_layer(float *lds, int wp, int hin, int hout, int wave,
-                                               int lane, int i, int g)
+// The conv stack is column-local (every kernel has width 1): column tile n0 of a layer's output
+// needs only column tile n0 of its input.  Wave w < 6 therefore owns column tile w through conv1
+// .. conv4 (and back through conv4 .. conv2 in the backward pass) with no workgroup barrier in
+// between -- its own LDS writes are read back by its own lanes, in program order -- and runs the
+// two 16-row output tiles of a layer as two interleaved MFMA chains (each unit is one dependent
+// chain on a single accumulator and the phases are latency-bound: SQ counters showed the MFMA
+// pipe 41 % busy with the waves waiting 56 % of the time).
+template <int K>   // K = Cin; Cout = 32
+__device__ __forceinline__ void conv_fwd_col(float *lds, int wp, int hin, int hout, int c0,
+                                             int lane, int i, int g)
 {
-    constexpr int UNITS = (O / 16) * 6;
     constexpr int STEPS = K / 4 + 1;
-    static_assert(UNITS <= 2 * WAVES, "two units per wave at most");
-    if (wave >= UNITS) return;
-    const int u0 = wave, u1 = wave + WAVES;
-    const int o0 = (u0 / 6) * 16, c0 = (u0 % 6) * 16;
-    const float *a0 = lds + wp + (u0 / 6) * STEPS * 64 + lane;
+    const float *a0 = lds + wp + lane, *a1 = a0 + STEPS * 64;
     // rank-1 terms and bias as one MFMA step: A = [b, as, ae, 0], B = [1, s, e, 0]
-    const float *ee = lds + L_EE + g * NP + i;            // EE rows 0..3 = 1, s, e, 0
-    const float *hb = lds + hin + (K / 4) * g * NP + i;
-    if (u1 < UNITS) {
-        const int o1 = (u1 / 6) * 16, c1 = (u1 % 6) * 16;
-        const float *a1 = lds + wp + (u1 / 6) * STEPS * 64 + lane;
-        f32x4 acc0 = mma(a0[0], ee[c0], (f32x4){0.f, 0.f, 0.f, 0.f});
-        f32x4 acc1 = mma(a1[0], ee[c1], (f32x4){0.f, 0.f, 0.f, 0.f});
+    const float ee = lds[L_EE + g * NP + c0 + i];         // EE rows 0..3 = 1, s, e, 0
+    const float *hb = lds + hin + (K / 4) * g * NP + c0 + i;
+    f32x4 acc0 = mma(a0[0], ee, (f32x4){0.f, 0.f, 0.f, 0.f});
+    f32x4 acc1 = mma(a1[0], ee, (f32x4){0.f, 0.f, 0.f, 0.f});
 #pragma unroll
-        for (int t = 0; t < K / 4; ++t) {
-            acc0 = mma(a0[(t + 1) * 64], hb[t * NP + c0], acc0);
-            acc1 = mma(a1[(t + 1) * 64], hb[t * NP + c1], acc1);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { acc0[r] = fmaxf(acc0[r], 0.0f); acc1[r] = fmaxf(acc1[r], 0.0f); }
-        put_tile(lds + hout, NP, o0, c0, acc0, i, g);
-        put_tile(lds + hout, NP, o1, c1, acc1, i, g);
-    } else {
-        f32x4 acc = mma(a0[0], ee[c0], (f32x4){0.f, 0.f, 0.f, 0.f});
-#pragma unroll
-        for (int t = 0; t < K / 4; ++t) acc = mma(a0[(t + 1) * 64], hb[t * NP + c0], acc);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = fmaxf(acc[r], 0.0f);
-        put_tile(lds + hout, NP, o0, c0, acc, i, g);
+    for (int t = 0; t < K / 4; ++t) {
+        const float b = hb[t * NP];
+        acc0 = mma(a0[(t + 1) * 64], b, acc0);
+        acc1 = mma(a1[(t + 1) * 64], b, acc1);
     }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { acc0[r] = fmaxf(acc0[r], 0.0f); acc1[r] = fmaxf(acc1[r], 0.0f); }
+    put_tile(lds + hout, NP, 0, c0, acc0, i, g);
+    put_tile(lds + hout, NP, 16, c0, acc1, i, g);
 }
 
-// backward-data of a conv layer: dZin[c][n] = relu'(Hin[c][n]) * sum_o Wm[o][c] dZout[o][n]
-template <int K, int O>   // K = Cin (rows produced), O = Cout (contraction)
-__device__ __forceinline__ void conv_bwd_data_layer(float *lds, int wp, int zout, int hin, int zin,
-                                                    int wave, int lane, int i, int g)
+// backward-data of a conv layer for one column tile:
+// dZin[c][n] = relu'(Hin[c][n]) * sum_o Wm[o][c] dZout[o][n];  K = Cin (16 or 32 rows), Cout = 32
+template <int K>
+__device__ __forceinline__ void conv_bwd_col(float *lds, int wp, int zout, int hin, int zin, int n0,
+                                             int lane, int i, int g)
 {
-    constexpr int UNITS = (K / 16) * 6;
-    static_assert(UNITS <= 2 * WAVES, "two units per wave at most");
-    if (wave >= UNITS) return;
-    const int u0 = wave, u1 = wave + WAVES;
-    const int c0 = (u0 / 6) * 16, n0 = (u0 % 6) * 16;
-    const float *a0 = lds + wp + (u0 / 6) * (O / 4) * 64 + lane;
-    const float *zb = lds + zout + (O / 4) * g * NP + i;
-    if (u1 < UNITS) {
-        const int c1 = (u1 / 6) * 16, n1 = (u1 % 6) * 16;
-        const float *a1 = lds + wp + (u1 / 6) * (O / 4) * 64 + lane;
-        f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float *a0 = lds + wp + lane, *a1 = a0 + 8 * 64;
+    const float *zb = lds + zout + 8 * g * NP + n0 + i;
+    f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int t = 0; t < O / 4; ++t) {
-            acc0 = mma(a0[t * 64], zb[t * NP + n0], acc0);
-            acc1 = mma(a1[t * 64], zb[t * NP + n1], acc1);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float h0 = lds[hin + (c0 + 4 * g + r) * NP + n0 + i];
-            const float h1 = lds[hin + (c1 + 4 * g + r) * NP + n1 + i];
-            acc0[r] = h0 > 0.0f ? acc0[r] : 0.0f;
-            acc1[r] = h1 > 0.0f ? acc1[r] : 0.0f;
-        }
-        put_tile(lds + zin, NP, c0, n0, acc0, i, g);
-        put_tile(lds + zin, NP, c1, n1, acc1, i, g);
-    } else {
-        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int t = 0; t < O / 4; ++t) acc = mma(a0[t * 64], zb[t * NP + n0], acc);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float hv = lds[hin + (c0 + 4 * g + r) * NP + n0 + i];
-            acc[r] = hv > 0.0f ? acc[r] : 0.0f;
-        }
-        put_tile(lds + zin, NP, c0, n0, acc, i, g);
+    for (int t = 0; t < 8; ++t) {
+        const float b = zb[t * NP];
+        acc0 = mma(a0[t * 64], b, acc0);
+        if (K == 32) acc1 = mma(a1[t * 64], b, acc1);
     }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        acc0[r] = lds[hin + (4 * g + r) * NP + n0 + i] > 0.0f ? acc0[r] : 0.0f;
+        if (K == 32) acc1[r] = lds[hin + (16 + 4 * g + r) * NP + n0 + i] > 0.0f ? acc1[r] : 0.0f;
+    }
+    put_tile(lds + zin, NP, 0, n0, acc0, i, g);
+    if (K == 32) put_tile(lds + zin, NP, 16, n0, acc1, i, g);
 }
 
-// fill the packed operands of a forward conv layer (see conv_fwd_layer)
+// fill the packed operands of a forward conv layer (see conv_fwd_col)
 template <int K>
 __device__ __forceinline__ void pack_conv_fwd(float *lds, int wp, const float *__restrict__ wmid,
                                               const float *__restrict__ bias, int aux, int tid)
@@ -264,13 +248,30 @@ __device__ __forceinline__ int grad_tile_of(int s, int w)
     return id < NTILES ? id : -1;
 }
 
+#ifdef WM_MODEL_STAMPS
+// debug build only (tools/probe/model_stamps.py): cycle stamps of wave 0 of workgroup 0 at the
+// phase boundaries of its 10th tile
+__device__ unsigned long long wm_stamps[32];
+#define STAMP(k)                                                                     \
+    do {                                                                             \
+        if (blockIdx.x == 0 && tid == 0 && tile == (long long)blockIdx.x + 10ll * gridDim.x) \
+            wm_stamps[k] = clock64();                                                \
+    } while (0)
+extern "C" int wm_debug_read_stamps(unsigned long long *dst)
+{
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(wm_stamps), sizeof(unsigned long long) * 32);
+}
+#else
+#define STAMP(k)
+#endif
+
 // MODE 0: forward only.  MODE 1: forward + backward with dL/dout = 2 (out - y) * dscale (fused
 // MSE).  MODE 2: forward + backward with dL/dout given.
 template <int MODE>
 __global__ __launch_bounds__(THREADS) void model_kernel(
     const float *__restrict__ prm, const float *__restrict__ x, const float *__restrict__ y,
     const float *__restrict__ dout, float *__restrict__ out, float *__restrict__ gtiles,
-    float *__restrict__ loss_part, long long B, float dscale)
+    float *__restrict__ loss_part, long long B, float dscale, const float *__restrict__ l1pack)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -322,111 +323,135 @@ __global__ __launch_bounds__(THREADS) void model_kernel(
     }
     __syncthreads();
 
-    // linear1 operands stay in registers: the forward unit of this wave (j-tile, w-half) and its
-    // three backward half-units (c-tile, w, j-half) never change
-    float l1f[L1F_R * 24];
-#pragma unroll
-    for (int r = 0; r < L1F_R; ++r) {
-        const int u = wave + WAVES * r, jt = u >> 1, half = u & 1, j = jt * 16 + i;
+    // linear1 operands (48 values per lane: the forward unit of this wave (j-tile, w-half) and its
+    // three backward half-units (c-tile, w, j-half)).  Forward-only launches keep the forward set
+    // in registers.  Training launches do not: with the 40 gradient accumulators the 48 values
+    // did not fit the 256 registers of a wave (23 spilled, and every reload at the head of a
+    // phase exposed a scratch round trip: 1.5 k of the 28 k cycles of a tile in the first phase
+    // alone).  They are re-read per tile from a lane-ordered copy in the workspace (l1pack, 96
+    // KB, L2-resident, six 16-byte loads per set) one phase before they are needed.
+    float l1f[24];
+    if constexpr (MODE == 0) {
+        const int jt = wave >> 1, half = wave & 1, j = jt * 16 + i;
 #pragma unroll
         for (int ww = 0; ww < 3; ++ww)
 #pragma unroll
             for (int t = 0; t < 8; ++t)
-                l1f[r * 24 + ww * 8 + t] = prm[P_L1W + j * 192 + (t + 8 * g) * 6 + half * 3 + ww];
+                l1f[ww * 8 + t] = prm[P_L1W + j * 192 + (t + 8 * g) * 6 + half * 3 + ww];
     }
-    float l1b[L1B_R * 8];
-    if constexpr (MODE != 0) {
-#pragma unroll
-        for (int r = 0; r < L1B_R; ++r) {
-            const int h = wave + WAVES * r, jh = h / 12, u = h % 12, ct = u / 6, w = u % 6;
-#pragma unroll
-            for (int t = 0; t < 8; ++t)
-                l1b[r * 8 + t] = prm[P_L1W + (8 * jh + t + 16 * g) * 192 + (ct * 16 + i) * 6 + w];
-        }
-    }
+    f32x4 lf[6], lb[6];
+    (void)lf; (void)lb;
 
     const long long ntiles = (B + TS - 1) / TS;
     // x of the NEXT tile is fetched while the current one is computed (one float per thread)
     const int xr = tid / NC, xcol = tid % NC, xoff = xr * 6 + (xcol >> 4), xs = xcol & 15;
+    // every load below is unconditional on a clamped index and its validity is applied where the
+    // value is used: a data-dependent branch around a load makes hipcc drain vmcnt(0) at the join
+    // (1.8 k cycles of HBM latency per tile, measured with cycle stamps)
     float xnext = 0.0f;
+    bool xvalid = false;
     if (tid < 2 * NC && (long long)blockIdx.x < ntiles) {
         const long long smp = (long long)blockIdx.x * TS + xs;
-        xnext = smp < B ? x[smp * 12 + xoff] : 0.0f;
+        xvalid = smp < B;
+        xnext = x[(smp < B ? smp : B - 1) * 12 + xoff];
     }
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long long s0 = tile * TS;
+        STAMP(0);
         // ---- x: XS[r][w*16+s] = x[s][r][w]; EE rows 1,2 mirror it
         if (tid < 2 * NC) {
-            lds[L_XS + xr * NP + xcol] = xnext;
-            lds[L_EE + (1 + xr) * NP + xcol] = xnext;
+            const float xv = xvalid ? xnext : 0.0f;
+            lds[L_XS + xr * NP + xcol] = xv;
+            lds[L_EE + (1 + xr) * NP + xcol] = xv;
             const long long smp = (tile + gridDim.x) * TS + xs;
-            xnext = (tile + gridDim.x < ntiles && smp < B) ? x[smp * 12 + xoff] : 0.0f;
+            xvalid = tile + gridDim.x < ntiles && smp < B;
+            xnext = x[(smp < B ? smp : B - 1) * 12 + xoff];
         }
-        // targets (or upstream gradient) of this tile, consumed by wave 0 after linear2
+        if constexpr (MODE != 0) {
+            // opaque per-tile copy of the lane offset: otherwise the loads are loop-invariant and
+            // hipcc hoists them back into 24 registers for the whole kernel (the base stays a
+            // kernel argument so that these are global, not flat, loads)
+            unsigned lo = (unsigned)((wave * 12 * 64 + lane) * 16);
+            asm volatile("" : "+v"(lo));
+#pragma unroll
+            for (int q = 0; q < 6; ++q) lf[q] = *(const f32x4 *)((const char *)l1pack + lo + q * 1024);
+        }
+        // targets (or upstream gradient) of this tile, consumed by wave 0 after linear2 (only for
+        // m < 6 and samples < B; the rest are reads of clamped entries that are never used)
         float tgt[4] = {0.f, 0.f, 0.f, 0.f};
         if constexpr (MODE != 0) {
             if (wave == 0) {
-                const long long smp = s0 + i;
+                const long long smp = s0 + i < B ? s0 + i : B - 1;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int m = 4 * g + r;
-                    if (m < 6 && smp < B) tgt[r] = MODE == 1 ? y[smp * 6 + m] : dout[smp * 6 + m];
+                    const int m = 4 * g + r < 6 ? 4 * g + r : 5;
+                    tgt[r] = MODE == 1 ? y[smp * 6 + m] : dout[smp * 6 + m];
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();        // the x of the next tile and this tile's targets stay in flight
+        STAMP(1);
         // ---- forward
         // conv1 weight (16,1,2,1): as = W[o][0][0], ae = W[o][0][1]  (strided view)
-        {
-            constexpr int UNITS = 6;
-            for (int u = wave; u < UNITS; u += WAVES) {
-                const int c0 = u * 16;
-                const float a0 = lds[W_C1F + lane];
-                const float b0 = lds[L_EE + g * NP + c0 + i];
-                f32x4 acc = mma(a0, b0, (f32x4){0.f, 0.f, 0.f, 0.f});
+        if (wave < 6) {
+            const int c0 = wave * 16;
+            const float a0 = lds[W_C1F + lane];
+            const float b0 = lds[L_EE + g * NP + c0 + i];
+            f32x4 acc = mma(a0, b0, (f32x4){0.f, 0.f, 0.f, 0.f});
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[r] = fmaxf(acc[r], 0.0f);
-                put_tile(lds + L_H1, NP, 0, c0, acc, i, g);
-            }
+            for (int r = 0; r < 4; ++r) acc[r] = fmaxf(acc[r], 0.0f);
+            put_tile(lds + L_H1, NP, 0, c0, acc, i, g);
+            conv_fwd_col<16>(lds, W_C2F, L_H1, L_H2, c0, lane, i, g);
+            conv_fwd_col<32>(lds, W_C3F, L_H2, L_H3, c0, lane, i, g);
+            conv_fwd_col<32>(lds, W_C4F, L_H3, L_H4, c0, lane, i, g);
         }
-        __syncthreads();
-        conv_fwd_layer<16, 32>(lds, W_C2F, L_H1, L_H2, wave, lane, i, g);
-        __syncthreads();
-        conv_fwd_layer<32, 32>(lds, W_C3F, L_H2, L_H3, wave, lane, i, g);
-        __syncthreads();
-        conv_fwd_layer<32, 32>(lds, W_C4F, L_H3, L_H4, wave, lane, i, g);
-        __syncthreads();
+        lds_barrier();
+        STAMP(2);
         // linear1: u[j][s] = sum_w sum_c L1[j][c*6+w] H4[c][w*16+s]; 8 units = 4 j-tiles x 2 w-halves
-#pragma unroll
-        for (int r = 0; r < L1F_R; ++r) {
-            const int u = wave + WAVES * r, jt = u >> 1, half = u & 1;
+        {
+            const int jt = wave >> 1, half = wave & 1;
             f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ww = 0; ww < 3; ++ww) {
                 const int w = half * 3 + ww;
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
-                    const int c = t + 8 * g;
-                    acc = mma(l1f[r * 24 + ww * 8 + t], lds[L_H4 + c * NP + w * 16 + i], acc);
+                    const int c = t + 8 * g, e = ww * 8 + t;
+                    const float a = MODE == 0 ? l1f[e] : lf[e >> 2][e & 3];
+                    acc = mma(a, lds[L_H4 + c * NP + w * 16 + i], acc);
                 }
             }
             put_tile(lds + L_UU + half * 64 * SP, SP, jt * 16, 0, acc, i, g);
         }
-        __syncthreads();
+        if constexpr (MODE != 0) {
+            // the backward set, needed four phases from here
+            unsigned lo = (unsigned)(((wave * 12 + 6) * 64 + lane) * 16);
+            asm volatile("" : "+v"(lo));
+#pragma unroll
+            for (int q = 0; q < 6; ++q) lb[q] = *(const f32x4 *)((const char *)l1pack + lo + q * 1024);
+        }
+        lds_barrier();
+        STAMP(3);
         for (int e = tid; e < 64 * TS; e += THREADS) {
             const int j = e >> 4, s = e & 15;
             const float u = lds[L_UU + j * SP + s] + lds[L_UU + 64 * SP + j * SP + s] + lds[L_B1 + j];
-            lds[L_TT + j * SP + s] = tanhf(u);
+            lds[L_TT + j * SP + s] = fast_tanh(u);
         }
-        __syncthreads();
+        lds_barrier();
+        STAMP(4);
         // linear2: out[m][s] = bl2[m] + sum_j L2[m][j] T[j][s]   (one unit; rows m >= 6 are zero)
         if (wave == 0) {
-            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+            // four independent chains of four steps (one chain of 16 dependent MFMAs kept the
+            // other seven waves waiting 2.8 k cycles per tile), summed pairwise
+            f32x4 q0 = (f32x4){0.f, 0.f, 0.f, 0.f}, q1 = q0, q2 = q0, q3 = q0;
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const int j = t + 16 * g;
-                acc = mma(lds[W_L2F + t * 64 + lane], lds[L_TT + j * SP + i], acc);
+            for (int t = 0; t < 4; ++t) {
+                q0 = mma(lds[W_L2F + t * 64 + lane], lds[L_TT + (t + 16 * g) * SP + i], q0);
+                q1 = mma(lds[W_L2F + (t + 4) * 64 + lane], lds[L_TT + (t + 4 + 16 * g) * SP + i], q1);
+                q2 = mma(lds[W_L2F + (t + 8) * 64 + lane], lds[L_TT + (t + 8 + 16 * g) * SP + i], q2);
+                q3 = mma(lds[W_L2F + (t + 12) * 64 + lane], lds[L_TT + (t + 12 + 16 * g) * SP + i], q3);
             }
+            const f32x4 acc = (q0 + q1) + (q2 + q3);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = 4 * g + r;
@@ -452,10 +477,12 @@ __global__ __launch_bounds__(THREADS) void model_kernel(
             }
         }
         if constexpr (MODE == 0) {
-            __syncthreads();
+            lds_barrier();
+        STAMP(5);
             continue;
         }
-        __syncthreads();
+        lds_barrier();
+        STAMP(6);
         // ---- backward (data path)
         // dT[j][s] = sum_m L2[m][j] dO[m][s];  dU = dT (1 - T^2): 4 units (j-tiles)
         if (wave < 4) {
@@ -472,7 +499,8 @@ __global__ __launch_bounds__(THREADS) void model_kernel(
             }
             put_tile(lds + L_DU, SP, wave * 16, 0, acc, i, g);
         }
-        __syncthreads();
+        lds_barrier();
+        STAMP(7);
         // dH4[c][w*16+s] = sum_j L1[j][c*6+w] dU[j][s]: 24 half-units (c-tile, w, j-half), three
         // per wave; the halves land in Z4 and (scratch) Z3 and are summed under the ReLU mask
 #pragma unroll
@@ -482,22 +510,26 @@ __global__ __launch_bounds__(THREADS) void model_kernel(
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
                 const int j = 8 * jh + t + 16 * g;
-                acc = mma(l1b[r * 8 + t], lds[L_DU + j * SP + i], acc);
+                acc = mma(lb[(r * 8 + t) >> 2][(r * 8 + t) & 3], lds[L_DU + j * SP + i], acc);
             }
             put_tile(lds + (jh ? L_Z3 : L_Z4), NP, ct * 16, w * 16, acc, i, g);
         }
-        __syncthreads();
+        lds_barrier();
+        STAMP(8);
         for (int e = tid; e < 32 * NC; e += THREADS) {
             const int c = e / NC, n = e % NC, a = c * NP + n;
             lds[L_Z4 + a] = lds[L_H4 + a] > 0.0f ? lds[L_Z4 + a] + lds[L_Z3 + a] : 0.0f;
         }
-        __syncthreads();
-        conv_bwd_data_layer<32, 32>(lds, W_C4B, L_Z4, L_H3, L_Z3, wave, lane, i, g);
-        __syncthreads();
-        conv_bwd_data_layer<32, 32>(lds, W_C3B, L_Z3, L_H2, L_Z2, wave, lane, i, g);
-        __syncthreads();
-        conv_bwd_data_layer<16, 32>(lds, W_C2B, L_Z2, L_H1, L_Z1, wave, lane, i, g);
-        __syncthreads();
+        lds_barrier();
+        STAMP(9);
+        if (wave < 6) {
+            const int n0 = wave * 16;
+            conv_bwd_col<32>(lds, W_C4B, L_Z4, L_H3, L_Z3, n0, lane, i, g);
+            conv_bwd_col<32>(lds, W_C3B, L_Z3, L_H2, L_Z2, n0, lane, i, g);
+            conv_bwd_col<16>(lds, W_C2B, L_Z2, L_H1, L_Z1, n0, lane, i, g);
+        }
+        lds_barrier();
+        STAMP(10);
         // ---- weight gradients: every tile owned by one wave, accumulated in registers
         // slots in pairs: two tiles with the same step count run as two interleaved chains
 #pragma unroll
@@ -535,7 +567,8 @@ __global__ __launch_bounds__(THREADS) void model_kernel(
                 gacc[s] = acc;
             }
         }
-        __syncthreads();
+        lds_barrier();
+        STAMP(11);
     }
 
     if constexpr (MODE != 0) {
@@ -660,10 +693,33 @@ int model_grid(long long B)
     return (int)g;
 }
 
+// lane-ordered copy of linear1.weight for the training kernel: [wave][12][lane][4] floats, slots
+// 0..23 = the forward operands of the wave's (j-tile, w-half) unit, 24..47 = its three backward
+// half-units (see model_kernel)
+constexpr size_t L1PACK_FLOATS = (size_t)WAVES * 48 * 64;
+__global__ __launch_bounds__(256) void model_pack_l1_kernel(const float *__restrict__ prm,
+                                                            float *__restrict__ l1pack)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int)L1PACK_FLOATS) return;
+    const int k = e & 3, lane = (e >> 2) & 63, q = (e >> 8) % 12, wave = e / (12 * 256);
+    const int slot = q * 4 + k, i = lane & 15, g = lane >> 4;
+    float v;
+    if (slot < 24) {
+        const int jt = wave >> 1, half = wave & 1, j = jt * 16 + i, ww = slot / 8, t = slot % 8;
+        v = prm[P_L1W + j * 192 + (t + 8 * g) * 6 + half * 3 + ww];
+    } else {
+        const int r = (slot - 24) / 8, t = (slot - 24) % 8;
+        const int h = wave + WAVES * r, jh = h / 12, u = h % 12, ct = u / 6, w = u % 6;
+        v = prm[P_L1W + (8 * jh + t + 16 * g) * 192 + (ct * 16 + i) * 6 + w];
+    }
+    l1pack[e] = v;
+}
+
 template <int MODE>
 int model_launch(const float *prm, const float *x, const float *y, const float *dout, float *out,
                  float *gtiles, float *loss_part, long long B, float dscale, int grid,
-                 hipStream_t st)
+                 hipStream_t st, float *l1pack = nullptr)
 {
     // per device: the attribute belongs to the function's image on the current device
     static bool attr_set_dev[64][3] = {};
@@ -675,8 +731,13 @@ int model_launch(const float *prm, const float *x, const float *y, const float *
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
         attr_set[MODE] = true;
     }
+    if (MODE != 0) {
+        hipLaunchKernelGGL(model_pack_l1_kernel, dim3((unsigned)((L1PACK_FLOATS + 255) / 256)),
+                           dim3(256), 0, st, prm, l1pack);
+        WM_LAUNCH_CHECK("model_pack_l1_kernel");
+    }
     hipLaunchKernelGGL((model_kernel<MODE>), dim3(grid), dim3(THREADS), LDS_BYTES, st, prm, x, y,
-                       dout, out, gtiles, loss_part, B, dscale);
+                       dout, out, gtiles, loss_part, B, dscale, (const float *)l1pack);
     WM_LAUNCH_CHECK("model_kernel");
     return WM_OK;
 }
@@ -690,7 +751,7 @@ extern "C" size_t wm_model_workspace_bytes(int64_t B)
     if (B <= 0 || wm_num_cus() <= 0) return 0;
     const size_t blocks = (size_t)wm_num_cus();
     return wm_align_up(blocks * NTILES * 256 * sizeof(float) + blocks * sizeof(float) + 256, 256) +
-           (size_t)GSPLIT * NTILES * 256 * sizeof(double);
+           (size_t)GSPLIT * NTILES * 256 * sizeof(double) + L1PACK_FLOATS * sizeof(float);
 }
 
 extern "C" int wm_model_fwd_f32(const float *params, const float *x, float *out, int64_t B,
@@ -724,11 +785,11 @@ extern "C" int wm_model_train_f32(const float *params, const float *x, const flo
     float *loss_part = gtiles + (size_t)wm_num_cus() * NTILES * 256;
     const float dscale = 1.0f / (6.0f * (float)B_global);
     int rc;
-    if (y) rc = model_launch<1>(params, x, y, nullptr, out, gtiles, loss_part, B, dscale, grid, st);
-    else   rc = model_launch<2>(params, x, nullptr, dout, out, gtiles, loss_part, B, dscale, grid, st);
+    float *l1pack = (float *)((char *)workspace + need - L1PACK_FLOATS * sizeof(float));
+    if (y) rc = model_launch<1>(params, x, y, nullptr, out, gtiles, loss_part, B, dscale, grid, st, l1pack);
+    else   rc = model_launch<2>(params, x, nullptr, dout, out, gtiles, loss_part, B, dscale, grid, st, l1pack);
     if (rc) return rc;
-    double *tsum = (double *)((char *)workspace + need -
-                              (size_t)GSPLIT * NTILES * 256 * sizeof(double));
+    double *tsum = (double *)((char *)l1pack - (size_t)GSPLIT * NTILES * 256 * sizeof(double));
     hipLaunchKernelGGL(model_tile_reduce_kernel, dim3(NTILES, GSPLIT), dim3(256), 0, st, gtiles, grid,
                        tsum);
     WM_LAUNCH_CHECK("model_tile_reduce_kernel");
