@@ -19,8 +19,11 @@ L = _lib.lib()
 buf = (ctypes.c_ulonglong * 32)()
 L.wm_debug_read_stamps.argtypes = [ctypes.c_void_p]
 assert L.wm_debug_read_stamps(ctypes.byref(buf)) == 0
-names = ["x->LDS", "conv1-4 fwd", "linear1", "tanh", "linear2+loss", "dT", "dH4 halves", "relu mask", "conv4-2 bwd", "weight grads"]
-st = [v for k, v in enumerate(list(buf)[:12]) if k != 5]
-for k, n in enumerate(names):
-    print(f"{n:16s} {st[k + 1] - st[k]:8d} clk")
-print(f"{'tile total':16s} {st[10] - st[0]:8d} clk")
+names = {1: "x->LDS", 2: "conv1-4 fwd", 3: "linear1", 4: "tanh", 6: "linear2+loss", 7: "dT",
+         10: "dH4 + conv4-2 bwd", 11: "weight grads"}
+st = list(buf)[:12]
+prev = st[0]
+for k in sorted(names):
+    print(f"{names[k]:20s} {st[k] - prev:8d} clk")
+    prev = st[k]
+print(f"{'tile total':20s} {st[11] - st[0]:8d} clk   (a stamp's own store can add a vmcnt wait to the phase after it)")

@@ -38,7 +38,7 @@ constexpr int WAVES = THREADS / 64;
 constexpr int NTILES = 74;      // weight-gradient tiles
 constexpr int SLOTS = (NTILES + WAVES - 1) / WAVES;
 constexpr int L1F_R = 8 / WAVES;        // linear1 forward units (j-tile, w-half) per wave
-constexpr int L1B_R = 24 / WAVES;       // linear1 backward half-units per wave
+
 static_assert(WAVES == 8, "unit and gradient-tile assignment is written for 8 waves");
 constexpr int NPARAM = 20566;
 
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(THREADS) void model_kernel(
             for (int t = 0; t < 8; ++t)
                 l1f[ww * 8 + t] = prm[P_L1W + j * 192 + (t + 8 * g) * 6 + half * 3 + ww];
     }
-    f32x4 lf[6], lb[6];
+    f32x4 lf[6], lb[8];
     (void)lf; (void)lb;
 
     const long long ntiles = (B + TS - 1) / TS;
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(THREADS) void model_kernel(
             // opaque per-tile copy of the lane offset: otherwise the loads are loop-invariant and
             // hipcc hoists them back into 24 registers for the whole kernel (the base stays a
             // kernel argument so that these are global, not flat, loads)
-            unsigned lo = (unsigned)((wave * 12 * 64 + lane) * 16);
+            unsigned lo = (unsigned)((wave * 14 * 64 + lane) * 16);
             asm volatile("" : "+v"(lo));
 #pragma unroll
             for (int q = 0; q < 6; ++q) lf[q] = *(const f32x4 *)((const char *)l1pack + lo + q * 1024);
@@ -425,10 +425,10 @@ __global__ __launch_bounds__(THREADS) void model_kernel(
         }
         if constexpr (MODE != 0) {
             // the backward set, needed four phases from here
-            unsigned lo = (unsigned)(((wave * 12 + 6) * 64 + lane) * 16);
+            unsigned lo = (unsigned)(((wave * 14 + 6) * 64 + lane) * 16);
             asm volatile("" : "+v"(lo));
 #pragma unroll
-            for (int q = 0; q < 6; ++q) lb[q] = *(const f32x4 *)((const char *)l1pack + lo + q * 1024);
+            for (int q = 0; q < 8; ++q) lb[q] = *(const f32x4 *)((const char *)l1pack + lo + q * 1024);
         }
         lds_barrier();
         STAMP(3);
@@ -501,29 +501,29 @@ __global__ __launch_bounds__(THREADS) void model_kernel(
         }
         lds_barrier();
         STAMP(7);
-        // dH4[c][w*16+s] = sum_j L1[j][c*6+w] dU[j][s]: 24 half-units (c-tile, w, j-half), three
-        // per wave; the halves land in Z4 and (scratch) Z3 and are summed under the ReLU mask
-#pragma unroll
-        for (int r = 0; r < L1B_R; ++r) {
-            const int h = wave + WAVES * r, jh = h / 12, u = h % 12, ct = u / 6, w = u % 6;
-            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const int j = 8 * jh + t + 16 * g;
-                acc = mma(lb[(r * 8 + t) >> 2][(r * 8 + t) & 3], lds[L_DU + j * SP + i], acc);
-            }
-            put_tile(lds + (jh ? L_Z3 : L_Z4), NP, ct * 16, w * 16, acc, i, g);
-        }
-        lds_barrier();
-        STAMP(8);
-        for (int e = tid; e < 32 * NC; e += THREADS) {
-            const int c = e / NC, n = e % NC, a = c * NP + n;
-            lds[L_Z4 + a] = lds[L_H4 + a] > 0.0f ? lds[L_Z4 + a] + lds[L_Z3 + a] : 0.0f;
-        }
-        lds_barrier();
-        STAMP(9);
+        // dH4[c][w*16+s] = relu'(H4) * sum_j L1[j][c*6+w] dU[j][s]: like the conv layers this is
+        // local to column tile w, so wave w < 6 runs its two c-tiles as two interleaved chains
+        // (they share the B operand) and goes straight on into the conv backward stack -- no
+        // half-unit sums, no mask pass, no barrier (those two phases took 3.7 k cycles of 26 k)
         if (wave < 6) {
             const int n0 = wave * 16;
+            {
+                const float *du = lds + L_DU + 16 * g * SP + i;
+                f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const float b = du[t * SP];
+                    acc0 = mma(lb[t >> 2][t & 3], b, acc0);
+                    acc1 = mma(lb[4 + (t >> 2)][t & 3], b, acc1);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    acc0[r] = lds[L_H4 + (4 * g + r) * NP + n0 + i] > 0.0f ? acc0[r] : 0.0f;
+                    acc1[r] = lds[L_H4 + (16 + 4 * g + r) * NP + n0 + i] > 0.0f ? acc1[r] : 0.0f;
+                }
+                put_tile(lds + L_Z4, NP, 0, n0, acc0, i, g);
+                put_tile(lds + L_Z4, NP, 16, n0, acc1, i, g);
+            }
             conv_bwd_col<32>(lds, W_C4B, L_Z4, L_H3, L_Z3, n0, lane, i, g);
             conv_bwd_col<32>(lds, W_C3B, L_Z3, L_H2, L_Z2, n0, lane, i, g);
             conv_bwd_col<16>(lds, W_C2B, L_Z2, L_H1, L_Z1, n0, lane, i, g);
@@ -693,25 +693,24 @@ int model_grid(long long B)
     return (int)g;
 }
 
-// lane-ordered copy of linear1.weight for the training kernel: [wave][12][lane][4] floats, slots
-// 0..23 = the forward operands of the wave's (j-tile, w-half) unit, 24..47 = its three backward
-// half-units (see model_kernel)
-constexpr size_t L1PACK_FLOATS = (size_t)WAVES * 48 * 64;
+// lane-ordered copy of linear1.weight for the training kernel: [wave][14][lane][4] floats, slots
+// 0..23 = the forward operands of the wave's (j-tile, w-half) unit, 24..55 = the backward operands
+// of column tile w = wave (two c-tiles x 16 steps; waves 6, 7 have none) -- see model_kernel
+constexpr size_t L1PACK_FLOATS = (size_t)WAVES * 56 * 64;
 __global__ __launch_bounds__(256) void model_pack_l1_kernel(const float *__restrict__ prm,
                                                             float *__restrict__ l1pack)
 {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= (int)L1PACK_FLOATS) return;
-    const int k = e & 3, lane = (e >> 2) & 63, q = (e >> 8) % 12, wave = e / (12 * 256);
+    const int k = e & 3, lane = (e >> 2) & 63, q = (e >> 8) % 14, wave = e / (14 * 256);
     const int slot = q * 4 + k, i = lane & 15, g = lane >> 4;
-    float v;
+    float v = 0.0f;
     if (slot < 24) {
         const int jt = wave >> 1, half = wave & 1, j = jt * 16 + i, ww = slot / 8, t = slot % 8;
         v = prm[P_L1W + j * 192 + (t + 8 * g) * 6 + half * 3 + ww];
-    } else {
-        const int r = (slot - 24) / 8, t = (slot - 24) % 8;
-        const int h = wave + WAVES * r, jh = h / 12, u = h % 12, ct = u / 6, w = u % 6;
-        v = prm[P_L1W + (8 * jh + t + 16 * g) * 192 + (ct * 16 + i) * 6 + w];
+    } else if (wave < 6) {
+        const int ct = (slot - 24) / 16, t = (slot - 24) % 16;
+        v = prm[P_L1W + (t + 16 * g) * 192 + (ct * 16 + i) * 6 + wave];
     }
     l1pack[e] = v;
 }
