@@ -150,7 +150,8 @@ int    wm_model_fwd_f32(const float *params, const float *x, float *out, int64_t
  * rank's share sum_local (out-y)^2 / (6*B_global)), or dout (B x 6) = dL/dout from autograd; the
  * other must be NULL.  grads: 20566 floats, same layout as params (overwritten, bitwise
  * reproducible).  B_global >= B is the batch the mean runs over (data parallel: all-reduce(sum)
- * grads afterwards). */
+ * grads afterwards).  The workspace (caller-owned, contents undefined afterwards) holds the
+ * per-workgroup gradient tiles, their float64 sums and a lane-ordered copy of linear1.weight. */
 size_t wm_model_workspace_bytes(int64_t B);
 int    wm_model_train_f32(const float *params, const float *x, const float *y, const float *dout,
                           float *out, float *loss, float *grads, void *workspace,
