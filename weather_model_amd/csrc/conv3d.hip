@@ -61,18 +61,18 @@ __device__ __forceinline__ void reduce_tiles(float *part, const f32x4 (&acc)[OT]
 // contraction (wave w takes k-steps w, w+4, ...) and the partial tiles are summed through LDS in
 // a fixed order.  With one wave per tile the second layer of the reference ((16,16,7,7,14) ->
 // (16,64,3,3,10): only 90 column tiles, K = 2000) ran 23 workgroups of 500 dependent steps.
-template <int OT>   // OT 16-row tiles of output channels
-__global__ __launch_bounds__(BLOCK) void conv3d_fwd_kernel(const float *__restrict__ x,
+template <int OT, int NW>   // OT 16-row tiles of output channels, NW waves splitting the contraction
+__global__ __launch_bounds__(NW * 64) void conv3d_fwd_kernel(const float *__restrict__ x,
                                                            const float *__restrict__ w,
                                                            const float *__restrict__ bias,
                                                            float *__restrict__ y, Dims3 d, int K,
                                                            int Ntot, int relu)
 {
     __shared__ int off[KCHUNK];
-    __shared__ float part[WAVES * OT * 256];
+    __shared__ float part[NW * OT * 256];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
     const int S = d.OD * d.OH * d.OW;
-    const int tile = blockIdx.x;
+    const int tile = blockIdx.x, ot0 = blockIdx.y * OT;   // grid.y splits the channel tiles
     int n = tile * 16 + j;
     if (n >= Ntot) n = Ntot - 1;                     // keep the gathers in bounds; never stored
     const int b_ = n / S, sp = n % S;
@@ -87,21 +87,21 @@ __global__ __launch_bounds__(BLOCK) void conv3d_fwd_kernel(const float *__restri
         const int kn = min(KCHUNK, K - kc);
         const int kn4 = (kn + 3) & ~3;
         __syncthreads();
-        for (int k = tid; k < kn4; k += BLOCK) off[k] = k < kn ? tap_offset(d, kc + k) : 0;
+        for (int k = tid; k < kn4; k += (NW * 64)) off[k] = k < kn ? tap_offset(d, kc + k) : 0;
         __syncthreads();
         // UNR steps' operands are all requested before the first MFMA consumes one (hipcc does
         // not unroll a loop around the MFMA builtin by itself, and one step = one L2 round trip)
-        for (int kb = 4 * wave; kb < kn4; kb += 4 * WAVES * UNR) {
+        for (int kb = 4 * wave; kb < kn4; kb += 4 * NW * UNR) {
             float xv[UNR], wv[UNR][OT];
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
-                const int k = kb + u * 4 * WAVES + g;
+                const int k = kb + u * 4 * NW + g;
                 const bool ok = k < kn;
                 const int kk = ok ? k : 0;
                 xv[u] = x[nbase + off[kk]];
 #pragma unroll
                 for (int t = 0; t < OT; ++t) {
-                    const int o = t * 16 + j;
+                    const int o = (ot0 + t) * 16 + j;
                     wv[u][t] = (ok && o < d.Cout) ? w[(size_t)o * K + kc + kk] : 0.0f;
                 }
             }
@@ -112,14 +112,14 @@ __global__ __launch_bounds__(BLOCK) void conv3d_fwd_kernel(const float *__restri
         }
     }
     reduce_tiles<OT>(part, acc, wave, lane);
-    for (int idx = tid; idx < OT * 256; idx += BLOCK) {
+    for (int idx = tid; idx < OT * 256; idx += (NW * 64)) {
         const int t = idx >> 8, l = (idx >> 2) & 63, r = idx & 3;
-        const int o = t * 16 + 4 * (l >> 4) + r;
+        const int o = (ot0 + t) * 16 + 4 * (l >> 4) + r;
         const int nn = tile * 16 + (l & 15);
         if (o >= d.Cout || nn >= Ntot) continue;
         float v = bias ? bias[o] : 0.0f;
 #pragma unroll
-        for (int wv = 0; wv < WAVES; ++wv) v += part[((wv * OT + t) * 64 + l) * 4 + r];
+        for (int wv = 0; wv < NW; ++wv) v += part[((wv * OT + t) * 64 + l) * 4 + r];
         if (relu) v = fmaxf(v, 0.0f);
         y[((size_t)(nn / S) * d.Cout + o) * S + nn % S] = v;
     }
@@ -344,14 +344,14 @@ __global__ __launch_bounds__(BLOCK) void conv3d_fwd_rows_kernel(const float *__r
 // ------------------------------------------------------------------------------ backward data
 // table entry for kk = (o,kd,kh,kw): o << 24 | kd << 16 | kh << 8 | kw.  Same decomposition as the
 // forward kernel: one workgroup per 16-position tile, the four waves split the contraction.
-template <int CT>   // CT 16-row tiles of input channels
-__global__ __launch_bounds__(BLOCK) void conv3d_bwd_data_kernel(const float *__restrict__ gy,
+template <int CT, int NW>   // CT 16-row tiles of input channels
+__global__ __launch_bounds__(NW * 64) void conv3d_bwd_data_kernel(const float *__restrict__ gy,
                                                                 const float *__restrict__ w,
                                                                 float *__restrict__ gx, Dims3 d,
                                                                 int K2, int Mtot)
 {
     __shared__ int tab[KCHUNK];
-    __shared__ float part[WAVES * CT * 256];
+    __shared__ float part[NW * CT * 256];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
     const int k3 = d.kD * d.kH * d.kW;
     const int S = d.OD * d.OH * d.OW, V = d.D * d.H * d.W;
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(BLOCK) void conv3d_bwd_data_kernel(const float *__r
         const int kn = min(KCHUNK, K2 - kc);
         const int kn4 = (kn + 3) & ~3;
         __syncthreads();
-        for (int k = tid; k < kn4; k += BLOCK) {
+        for (int k = tid; k < kn4; k += (NW * 64)) {
             int e = -1;                               // padding: never in range
             if (k < kn) {
                 const int kk = kc + k;
@@ -381,11 +381,11 @@ __global__ __launch_bounds__(BLOCK) void conv3d_bwd_data_kernel(const float *__r
             tab[k] = e;
         }
         __syncthreads();
-        for (int kb = 4 * wave; kb < kn4; kb += 4 * WAVES * UNR) {
+        for (int kb = 4 * wave; kb < kn4; kb += 4 * NW * UNR) {
             float gv[UNR], wv[UNR][CT];
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
-                const int k = kb + u * 4 * WAVES + g;
+                const int k = kb + u * 4 * NW + g;
                 const int e = k < kn4 ? tab[k] : -1;
                 const int o = (e >> 24) & 0x7f, kd = (e >> 16) & 0xff, kh = (e >> 8) & 0xff,
                           kw = e & 0xff;
@@ -409,14 +409,14 @@ __global__ __launch_bounds__(BLOCK) void conv3d_bwd_data_kernel(const float *__r
         }
     }
     reduce_tiles<CT>(part, acc, wave, lane);
-    for (int idx = tid; idx < CT * 256; idx += BLOCK) {
+    for (int idx = tid; idx < CT * 256; idx += (NW * 64)) {
         const int t = idx >> 8, l = (idx >> 2) & 63, r = idx & 3;
         const int c = t * 16 + 4 * (l >> 4) + r;
         const int mm = tile * 16 + (l & 15);
         if (c >= d.Cin || mm >= Mtot) continue;
         float v = 0.0f;
 #pragma unroll
-        for (int wv = 0; wv < WAVES; ++wv) v += part[((wv * CT + t) * 64 + l) * 4 + r];
+        for (int wv = 0; wv < NW; ++wv) v += part[((wv * CT + t) * 64 + l) * 4 + r];
         gx[((size_t)(mm / V) * d.Cin + c) * V + mm % V] = v;
     }
 }
@@ -1231,15 +1231,20 @@ extern "C" int wm_conv3d_fwd_f32(const float *x, const float *w, const float *b,
         return WM_OK;
     }
     const int blocks = (Ntot + 15) / 16;            // one workgroup per 16-column tile
-    if (ot == 1)
-        hipLaunchKernelGGL(conv3d_fwd_kernel<1>, dim3(blocks), dim3(BLOCK), 0, st, x, w, b, y, d, K,
-                           Ntot, relu);
-    else if (ot == 2)
-        hipLaunchKernelGGL(conv3d_fwd_kernel<2>, dim3(blocks), dim3(BLOCK), 0, st, x, w, b, y, d, K,
-                           Ntot, relu);
-    else
-        hipLaunchKernelGGL(conv3d_fwd_kernel<4>, dim3(blocks), dim3(BLOCK), 0, st, x, w, b, y, d, K,
-                           Ntot, relu);
+    // few tiles (the reference's second Conv3D layer has 90): eight waves split the contraction and
+    // the channel tiles go to grid.y (the kernel is bound by its scattered weight gathers)
+    const bool deep = blocks <= 4 * wm_num_cus();
+#define FWD_SPLITK(OT_)                                                                          \
+    if (deep)   /* one channel tile per workgroup: every workgroup gathers only its 16 rows of w */ \
+        hipLaunchKernelGGL((conv3d_fwd_kernel<1, 8>), dim3(blocks, ot), dim3(512), 0, st, x, w, b, y, \
+                           d, K, Ntot, relu);                                                    \
+    else                                                                                         \
+        hipLaunchKernelGGL((conv3d_fwd_kernel<OT_, 4>), dim3(blocks), dim3(256), 0, st, x, w, b, y, \
+                           d, K, Ntot, relu)
+    if (ot == 1) { FWD_SPLITK(1); }
+    else if (ot == 2) { FWD_SPLITK(2); }
+    else { FWD_SPLITK(4); }
+#undef FWD_SPLITK
     WM_LAUNCH_CHECK("conv3d_fwd_kernel");
     return WM_OK;
 }
@@ -1296,15 +1301,18 @@ extern "C" int wm_conv3d_bwd_data_f32(const float *gy, const float *w, float *gx
         return WM_OK;
     }
     const int blocks = (Mtot + 15) / 16;            // one workgroup per 16-position tile
-    if (ct == 1)
-        hipLaunchKernelGGL(conv3d_bwd_data_kernel<1>, dim3(blocks), dim3(BLOCK), 0, st, gy, w, gx, d,
-                           K2, Mtot);
-    else if (ct == 2)
-        hipLaunchKernelGGL(conv3d_bwd_data_kernel<2>, dim3(blocks), dim3(BLOCK), 0, st, gy, w, gx, d,
-                           K2, Mtot);
-    else
-        hipLaunchKernelGGL(conv3d_bwd_data_kernel<4>, dim3(blocks), dim3(BLOCK), 0, st, gy, w, gx, d,
-                           K2, Mtot);
+    const bool deep = blocks <= 4 * wm_num_cus();
+#define BWD_SPLITK(CT_)                                                                          \
+    if (deep)                                                                                    \
+        hipLaunchKernelGGL((conv3d_bwd_data_kernel<CT_, 8>), dim3(blocks), dim3(512), 0, st, gy, w, \
+                           gx, d, K2, Mtot);                                                     \
+    else                                                                                         \
+        hipLaunchKernelGGL((conv3d_bwd_data_kernel<CT_, 4>), dim3(blocks), dim3(256), 0, st, gy, w, \
+                           gx, d, K2, Mtot)
+    if (ct == 1) { BWD_SPLITK(1); }
+    else if (ct == 2) { BWD_SPLITK(2); }
+    else { BWD_SPLITK(4); }
+#undef BWD_SPLITK
     WM_LAUNCH_CHECK("conv3d_bwd_data_kernel");
     return WM_OK;
 }
