@@ -1005,6 +1005,97 @@ __global__ __launch_bounds__(BLOCK) WBR_WAVES_ATTR void conv3d_bwd_wb_rows_kerne
     }
 }
 
+// ------------------------------------------------------------------------------ backward w, b, small volumes
+// The reference's own Conv3D shapes ((16,1,20^3) x 7^3 and (16,16,7,7,14) x 5^3: rows of 14 and 10
+// outputs, 1e4..1e5 outputs in all) are far too small for the row kernel and made the generic
+// kernel above gather-bound (two scattered 16-line gathers per MFMA: 70 us per call, the largest
+// item of the model's training step).  Here a workgroup owns one output plane (b, od): its input
+// slab x[b, :, od..od+kD-1, :, :] and gy[b, :, od, :, :] are copied once into LDS, coalesced, and
+// both MFMA operands are LDS reads (B at tap offset + position offset, both from tiny tables).
+// grid = (B*OD planes, groups of WAVES*KTW tap tiles); a wave keeps KTW tap tiles x OT channel
+// tiles in registers over the plane and stores them as float64 to the plane's partial slab;
+// conv3d_reduce_kernel sums the B*OD slabs in a fixed order.
+template <int OT, int KTW>
+__global__ __launch_bounds__(BLOCK) void conv3d_bwd_wb_vol_kernel(const float *__restrict__ x,
+                                                                  const float *__restrict__ gy,
+                                                                  double *__restrict__ partial,
+                                                                  Dims3 d, int K)
+{
+    extern __shared__ __align__(16) float smem[];
+    const int HW = d.H * d.W, slabn = d.Cin * d.kD * HW, P = d.OH * d.OW, P4 = (P + 3) & ~3;
+    const int GP = P4 + 4;                               // gy row pitch
+    // [slabn] x slab | [HW] ones | [HW] zeros | [OT*16][GP] gy | [P4] position offsets
+    const int ones = slabn, zeros = ones + HW, goff = zeros + HW, poff = goff + OT * 16 * GP;
+    int *pos = (int *)(smem + poff);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
+    const int plane = blockIdx.x, b_ = plane / d.OD, od = plane - b_ * d.OD;
+
+    {
+        const int run = d.kD * HW;                        // contiguous floats per input channel
+        const float *src = x + ((size_t)b_ * d.Cin * d.D + od) * HW;
+        for (int e = tid; e < slabn; e += BLOCK) {
+            const int c = e / run, r = e - c * run;
+            smem[e] = src[(size_t)c * d.D * HW + r];
+        }
+        for (int e = tid; e < HW; e += BLOCK) { smem[ones + e] = 1.0f; smem[zeros + e] = 0.0f; }
+        const float *gsrc = gy + ((size_t)b_ * d.Cout * d.OD + od) * P;
+        for (int e = tid; e < OT * 16 * P4; e += BLOCK) {
+            const int o = e / P4, n = e - o * P4;
+            smem[goff + o * GP + n] = (o < d.Cout && n < P) ? gsrc[(size_t)o * d.OD * P + n] : 0.0f;
+        }
+        for (int n = tid; n < P4; n += BLOCK) pos[n] = n < P ? (n / d.OW) * d.W + n % d.OW : 0;
+    }
+    // this lane's B-operand base of tap tile q: tap k = ((group*KTW + q)*WAVES + wave)*16 + j
+    int koff[KTW];
+#pragma unroll
+    for (int q = 0; q < KTW; ++q) {
+        const int k = (((int)blockIdx.y * KTW + q) * WAVES + wave) * 16 + j;
+        int o_ = zeros;
+        if (k < K) {
+            const int kw = k % d.kW, t1 = k / d.kW, kh = t1 % d.kH, t2 = t1 / d.kH;   // t2 = c*kD + kd
+            o_ = t2 * HW + kh * d.W + kw;
+        } else if (k == K) {
+            o_ = ones;
+        }
+        koff[q] = o_;
+    }
+    f32x4 acc[KTW][OT];
+#pragma unroll
+    for (int q = 0; q < KTW; ++q)
+#pragma unroll
+        for (int t = 0; t < OT; ++t) acc[q][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    const int abase = goff + j * GP + g;
+    for (int s_ = 0; s_ < P4; s_ += 4) {
+        const int po = pos[s_ + g];
+        float a[OT], bq[KTW];
+#pragma unroll
+        for (int t = 0; t < OT; ++t) a[t] = smem[abase + t * 16 * GP + s_];
+#pragma unroll
+        for (int q = 0; q < KTW; ++q) bq[q] = smem[koff[q] + po];
+#pragma unroll
+        for (int q = 0; q < KTW; ++q)
+#pragma unroll
+            for (int t = 0; t < OT; ++t) acc[q][t] = mma(a[t], bq[q], acc[q][t]);
+    }
+    const int nw = d.Cout * K, nent = nw + d.Cout;
+    double *dst = partial + (size_t)plane * nent;
+#pragma unroll
+    for (int q = 0; q < KTW; ++q) {
+        const int k_b = (((int)blockIdx.y * KTW + q) * WAVES + wave) * 16 + j;
+#pragma unroll
+        for (int t = 0; t < OT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = t * 16 + 4 * g + r;
+                if (o < d.Cout) {
+                    if (k_b < K) dst[(size_t)o * K + k_b] = (double)acc[q][t][r];
+                    else if (k_b == K) dst[nw + o] = (double)acc[q][t][r];
+                }
+            }
+    }
+}
+
 __global__ __launch_bounds__(64) void conv3d_reduce_kernel(const double *__restrict__ partial,
                                                            int nparts, int nent, int nw,
                                                            float *__restrict__ gw,
@@ -1016,6 +1107,30 @@ __global__ __launch_bounds__(64) void conv3d_reduce_kernel(const double *__restr
     for (int p = 0; p < nparts; ++p) s += partial[(size_t)p * nent + e];
     if (e < nw) gw[e] = (float)s;
     else if (gb) gb[e - nw] = (float)s;
+}
+
+// conv3d_reduce_kernel for many slabs: 64 entries x 16 slab groups per workgroup, group partials
+// combined through LDS in a fixed order
+__global__ __launch_bounds__(1024) void conv3d_reduce16_kernel(const double *__restrict__ partial,
+                                                               int nparts, int nent, int nw,
+                                                               float *__restrict__ gw,
+                                                               float *__restrict__ gb)
+{
+    __shared__ double part[16][64];
+    const int le = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + le;
+    double s = 0.0;
+    if (e < nent)
+        for (int p = grp; p < nparts; p += 16) s += partial[(size_t)p * nent + e];
+    part[grp][le] = s;
+    __syncthreads();
+    if (grp == 0 && e < nent) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += part[q][le];
+        if (e < nw) gw[e] = (float)t;
+        else if (gb) gb[e - nw] = (float)t;
+    }
 }
 
 // the same sum for many slabs (one per persistent workgroup): 64 entries x 16 slab groups per
@@ -1107,6 +1222,39 @@ bool wb_wide_shape(long long Ntot, int K)
 {
     const int cus = wm_num_cus();
     return cus > 0 && Ntot >= 4096ll * cus && (K + 1 + 15) / 16 <= 8 * WAVES;
+}
+
+// The small-volume kernel: tap tiles per wave (1, 2 or 4), groups and LDS bytes, or false.
+bool wb_vol_plan(int B, int Cin, int D, int H, int W, int Cout, int kD, int kH, int kW, int *ktw,
+                 int *groups, size_t *lds)
+{
+    const int OD = D - kD + 1, OH = H - kH + 1, OW = W - kW + 1;
+    const int K = Cin * kD * kH * kW, P4 = (OH * OW + 3) & ~3;
+    const int otiles = (Cout + 15) / 16, ot = otiles == 3 ? 4 : otiles, ktiles = (K + 1 + 15) / 16;
+    const size_t bytes = ((size_t)Cin * kD * H * W + 2 * (size_t)H * W + (size_t)ot * 16 * (P4 + 4) +
+                          (size_t)P4) * sizeof(float);
+    if (bytes > RESIDENT_LDS || (long long)B * OD > 65535 || OW >= WBR_SEG) return false;
+    // as many tap tiles per wave as keep the accumulators at <= 16 tiles and the grid >= 2 per CU
+    int t = ot >= 4 ? 4 : (ot == 2 ? 4 : 8);
+    t = t > 4 ? 4 : t;
+    while (t > 1 && (long long)B * OD * ((ktiles + WAVES * t - 1) / (WAVES * t)) < 2ll * wm_num_cus()) t >>= 1;
+    *ktw = t;
+    *groups = (ktiles + WAVES * t - 1) / (WAVES * t);
+    *lds = bytes;
+    return true;
+}
+
+typedef void (*wb_vol_fn)(const float *, const float *, double *, Dims3, int);
+wb_vol_fn wb_vol_kernel(int otiles, int ktw)
+{
+#define WBV_K(OT_)                                                                \
+    return ktw == 1 ? conv3d_bwd_wb_vol_kernel<OT_, 1>                             \
+           : ktw == 2 ? conv3d_bwd_wb_vol_kernel<OT_, 2>                           \
+                      : conv3d_bwd_wb_vol_kernel<OT_, 4>
+    if (otiles == 1) { WBV_K(1); }
+    if (otiles == 2) { WBV_K(2); }
+    WBV_K(4);
+#undef WBV_K
 }
 
 // The LDS-staged row kernel: grid (a multiple of 8, one float64 slab per workgroup), LDS bytes and
@@ -1330,6 +1478,10 @@ extern "C" size_t wm_conv3d_bwd_wb_workspace_bytes(int B, int Cin, int D, int H,
     int rgrid = 0;
     size_t rlds = 0;
     if (wb_rows_plan(B, Cin, D, H, W, Cout, kD, kH, kW, &rgrid, &rlds)) splits = (size_t)rgrid;
+    int vktw = 0, vgroups = 0;
+    size_t vlds = 0;
+    if (!rgrid && wb_vol_plan(B, Cin, D, H, W, Cout, kD, kH, kW, &vktw, &vgroups, &vlds))
+        splits = (size_t)B * (D - kD + 1);                          // one slab per output plane
     return wm_align_up(splits * nent * sizeof(double), 256);
 }
 
@@ -1363,6 +1515,18 @@ extern "C" int wm_conv3d_bwd_wb_f32(const float *x, const float *gy, float *gw, 
         hipLaunchKernelGGL(conv3d_reduce_slabs_kernel, dim3((nent + 63) / 64), dim3(1024), 0, st,
                            (const double *)workspace, rgrid, Cout, K, gw, gb);
         WM_LAUNCH_CHECK("conv3d_reduce_slabs_kernel");
+        return WM_OK;
+    }
+    int vktw = 0, vgroups = 0;
+    size_t vlds = 0;
+    if (wb_vol_plan(B, Cin, D, H, W, Cout, kD, kH, kW, &vktw, &vgroups, &vlds)) {
+        const int planes = B * d.OD;
+        hipLaunchKernelGGL(wb_vol_kernel(otiles, vktw), dim3(planes, vgroups), dim3(BLOCK), vlds, st,
+                           x, gy, (double *)workspace, d, K);
+        WM_LAUNCH_CHECK("conv3d_bwd_wb_vol_kernel");
+        hipLaunchKernelGGL(conv3d_reduce16_kernel, dim3((nent + 63) / 64), dim3(1024), 0, st,
+                           (const double *)workspace, planes, nent, nw, gw, gb);
+        WM_LAUNCH_CHECK("conv3d_reduce16_kernel");
         return WM_OK;
     }
     if (wb_wide_shape(Ntot, K)) {
