@@ -434,6 +434,42 @@ def run_conv32(steps, warmup, rank, world, cpu_base, N=8, C=32, H=721, W=1440):
                          "TFLOPs": {k: flops_pass / (v * 1e-3) / 1e12 for k, v in ms.items()}}}
 
 
+# ------------------------------------------------------------------------------ Conv3D model
+def run_conv3d_model(steps, warmup, batch=16):
+    """the reference's Conv3D network (convolution.py:156-180) at its own shapes,
+    input (1,20,20,20), batch 16: one training step (two conv branches forward and backward, pools,
+    two dense layers, Adam) replayed from a HIP graph.  Single GPU only (the reference path has no
+    data-parallel exchange)."""
+    from weather_model_amd.dropin._conv3d_model import Conv3DModel
+    m = Conv3DModel((1, 20, 20, 20), seed=0)
+    m.compile()
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    x1 = torch.rand((batch, 1, 20, 20, 20), device="cuda", generator=gen)
+    x2 = torch.rand((batch, 1, 20, 20, 20), device="cuda", generator=gen)
+    y = torch.rand((batch, 1, 8000), device="cuda", generator=gen)
+    for _ in range(max(warmup, 3)):
+        m.graphed_train_step((x1, x2, y))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        logs = m.graphed_train_step((x1, x2, y))
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    # 2 branches x (layer 1: 16*14^3 outputs x 32 x 343, layer 2: 16*3*3*10 x 64 x 2000) MACs forward,
+    # the same again for the weight gradients, layer 2 once more for its input gradient; dense
+    # layers 640x640 and 640x8000 forward + 2x backward
+    conv = 2 * 2.0 * batch * (14 ** 3 * 32 * 343 + 90 * 64 * 2000)
+    flops = 2 * conv + 2 * 2.0 * batch * 90 * 64 * 2000 + 3 * 2.0 * batch * (640 * 640 + 640 * 8000)
+    return {"value": batch / dt, "unit": "samples/s", "ms_per_step": dt * 1e3, "loss": logs["loss"],
+            "config": {"workload": f"Conv3D interpolation model, input (1,20,20,20), batch {batch}, "
+                                   "fit step (HIP-graph replay)"},
+            "roofline": {"bound": "mfma", "achieved": flops / dt / 1e12, "peak": MFMA_F32_PEAK_TF,
+                         "unit": "TFLOP/s", "frac": flops / dt / 1e12 / MFMA_F32_PEAK_TF,
+                         "traffic": None, "kernel": "conv3d split-K / small-volume kernels (gather-"
+                                                    "and launch-bound at these sizes)",
+                         "algorithmic_flops_per_step": flops}}
+
+
 # ------------------------------------------------------------------------------ field kernels
 def run_fields(steps, warmup, rank, world, cpu_base):
     """one-pass statistics, normalise and the sample gather, each on a
@@ -513,7 +549,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="all", choices=["all", "gram16", "conv3x3", "gram64", "model32", "fields", "conv32"])
+    ap.add_argument("--workload", default="all", choices=["all", "gram16", "conv3x3", "gram64", "model32", "fields", "conv32", "conv3d_model"])
     ap.add_argument("--rows", type=int, default=100_000_000, help="rows per GPU (gram workloads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -584,6 +620,14 @@ def main():
                 out["cpu_baseline"] = fres["cpu_baseline"]
         else:
             out.setdefault("also", {})["fields"] = fres
+    if args.workload in ("all", "conv3d_model") and world == 1:
+        c3 = run_conv3d_model(args.steps, args.warmup)
+        if args.workload == "conv3d_model":
+            out.update({"metric": "samples/s Conv3D model fit step", "unit": "samples/s",
+                        "value": c3["value"], "ms_per_step": c3["ms_per_step"],
+                        "roofline": c3["roofline"], "config": c3["config"]})
+        else:
+            out.setdefault("also", {})["conv3d_model"] = c3
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
