@@ -125,3 +125,25 @@ def test_graphed_train_step_matches_eager():
     np.testing.assert_allclose(la, lb, rtol=1e-5)
     for k in a.params:
         assert relinf(b.params[k].detach().cpu().numpy(), a.params[k].detach().cpu().numpy()) < 1e-5, k
+
+
+def test_graphed_step_keeps_one_graph_per_batch_shape():
+    """Alternating batch sizes (the short last batch of an epoch) replay their own graphs and stay
+    on the eager trajectory."""
+    from weather_model_amd.dropin._conv3d_model import Conv3DModel
+    a = Conv3DModel((1, 20, 20, 20), seed=6)
+    b = Conv3DModel((1, 20, 20, 20), seed=6)
+    a.compile()
+    b.compile()
+    rng = np.random.default_rng(2)
+
+    def batch(n):
+        return (rng.uniform(size=(n, 1, 20, 20, 20)).astype(np.float32),
+                rng.uniform(size=(n, 1, 20, 20, 20)).astype(np.float32),
+                rng.uniform(size=(n, 1, 8000)).astype(np.float32))
+
+    batches = [batch(n) for n in (4, 2, 4, 2)]
+    la = [a.train_step(bt)["loss"] for bt in batches]
+    lb = [b.graphed_train_step(bt)["loss"] for bt in batches]
+    assert len(b._graphs) == 2
+    np.testing.assert_allclose(la, lb, rtol=1e-5)

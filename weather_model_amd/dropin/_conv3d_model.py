@@ -185,8 +185,9 @@ class Conv3DModel:
             raise RuntimeError("compile the model before training")
         x1, x2, y = (self._to_dev(data[0]), self._to_dev(data[1]), self._targets(data[2]))
         key = (tuple(x1.shape), tuple(y.shape))
-        g = getattr(self, "_graph", None)
-        if g is None or g["key"] != key:
+        graphs = self.__dict__.setdefault("_graphs", {})     # one per batch shape (the last batch of
+        g = graphs.get(key)                                   # an epoch is usually shorter)
+        if g is None:
             g = {"key": key, "x1": x1.clone(), "x2": x2.clone(), "y": y.clone()}
 
             def body():
@@ -224,7 +225,7 @@ class Conv3DModel:
                             v.copy_(st[k]) if k in st else v.zero_()
             g["grads"] = [p.grad for p in plist]
             g["graph"] = graph
-            self._graph = g
+            graphs[key] = g
         for p, gr in zip(self.params.values(), g["grads"]):
             p.grad = gr                                  # an eager step in between may rebind them
         g["x1"].copy_(x1)
