@@ -67,6 +67,10 @@ CONV3D_LARGE_CASES = [
     # (K = 16), three channel tiles, planes of 80 positions; and a plane that is not a multiple of 4
     ("vol_bias_tile", 2, 4, (3, 9, 11), 40, (1, 2, 2), 38, 1),
     ("vol_odd_plane", 3, 5, (4, 6, 9), 7, (2, 2, 3), 39, 1),
+    # mid-size outputs with a deep contraction (the reference's
+    # second layer at batch 12; and two input-channel tiles with a ragged last one)
+    ("mid_bwd_data", 12, 16, (7, 7, 14), 64, (5, 5, 5), 40, 1),
+    ("mid_ct2", 3, 20, (8, 20, 20), 40, (3, 3, 3), 41, 1),
 ]
 
 
