@@ -71,6 +71,9 @@ CONV3D_LARGE_CASES = [
     # second layer at batch 12; and two input-channel tiles with a ragged last one)
     ("mid_bwd_data", 12, 16, (7, 7, 14), 64, (5, 5, 5), 40, 1),
     ("mid_ct2", 3, 20, (8, 20, 20), 40, (3, 3, 3), 41, 1),
+    # >= 128 output planes with weights + slab resident in LDS: the plane-resident forward kernel
+    ("vol_fwd", 10, 1, (20, 20, 20), 32, (7, 7, 7), 42, 1),
+    ("vol_fwd_ragged", 9, 3, (18, 9, 13), 20, (3, 2, 4), 43, 1),
 ]
 
 

@@ -125,6 +125,106 @@ __global__ __launch_bounds__(NW * 64) void conv3d_fwd_kernel(const float *__rest
     }
 }
 
+// ------------------------------------------------------------------------------ forward, small volumes
+// The first layer of the reference's Conv3D model ((16,1,20^3) x 7^3 -> 32 channels): the whole
+// packed weight matrix (44 KB) and the input slab of one output plane (b, od) fit in LDS together,
+// so a workgroup per plane reads both MFMA operands from LDS (tap offset + position offset, as in
+// conv3d_bwd_wb_vol_kernel) instead of gathering them per step (50 us for 1 GFLOP).  A wave takes
+// position tiles wave, wave+4, .. two at a time (2 OT independent chains).
+template <int OT>
+__global__ __launch_bounds__(BLOCK) void conv3d_fwd_vol_kernel(const float *__restrict__ x,
+                                                               const float *__restrict__ w,
+                                                               const float *__restrict__ bias,
+                                                               float *__restrict__ y, Dims3 d, int K,
+                                                               int relu)
+{
+    extern __shared__ __align__(16) float smem[];
+    const int HW = d.H * d.W, slabn = d.Cin * d.kD * HW, P = d.OH * d.OW, PT = (P + 15) >> 4;
+    const int steps = (((K + 3) >> 2) + 1) & ~1;         // even, padded with zero weights
+    // [slabn] x slab | [steps][OT][64] packed weights | [steps*4] tap offsets | [PT*16] positions
+    const int woff = slabn, toff_ = woff + steps * OT * 64, poff = toff_ + steps * 4;
+    float *wl = smem + woff;
+    int *tof = (int *)(smem + toff_), *pos = (int *)(smem + poff);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
+    const int plane = blockIdx.x, b_ = plane / d.OD, od = plane - b_ * d.OD;
+    {
+        const int run = d.kD * HW;
+        const float *src = x + ((size_t)b_ * d.Cin * d.D + od) * HW;
+        for (int e = tid; e < slabn; e += BLOCK) {
+            const int c = e / run, r = e - c * run;
+            smem[e] = src[(size_t)c * d.D * HW + r];
+        }
+        for (int e = tid; e < steps * OT * 64; e += BLOCK) wl[e] = 0.0f;
+        for (int k = tid; k < steps * 4; k += BLOCK) {
+            int o_ = 0;
+            if (k < K) {
+                const int kw = k % d.kW, t1 = k / d.kW, kh = t1 % d.kH, t2 = t1 / d.kH;
+                o_ = t2 * HW + kh * d.W + kw;
+            }
+            tof[k] = o_;
+        }
+        for (int n = tid; n < PT * 16; n += BLOCK) {
+            const int nc = n < P ? n : P - 1;             // clamped: computed, never stored
+            pos[n] = (nc / d.OW) * d.W + nc % d.OW;
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < d.Cout * K; e += BLOCK) {
+        const int o = e / K, k = e - o * K;
+        wl[((k >> 2) * OT + (o >> 4)) * 64 + (k & 3) * 16 + (o & 15)] = w[e];
+    }
+    __syncthreads();
+    float bv[OT][4];
+#pragma unroll
+    for (int t = 0; t < OT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int o = t * 16 + 4 * g + r;
+            bv[t][r] = (bias && o < d.Cout) ? bias[o] : 0.0f;
+        }
+    const size_t ybase = ((size_t)b_ * d.Cout * d.OD + od) * P;
+    for (int pt = wave; pt < PT; pt += 2 * WAVES) {
+        const int pt1 = pt + WAVES < PT ? pt + WAVES : pt;   // second tile (or a repeat)
+        const int p0 = pos[pt * 16 + j], p1 = pos[pt1 * 16 + j];
+        f32x4 acc0[OT], acc1[OT];
+#pragma unroll
+        for (int t = 0; t < OT; ++t) { acc0[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1[t] = acc0[t]; }
+        for (int s_ = 0; s_ < steps; s_ += 2) {
+            const int o0 = tof[4 * s_ + g], o1 = tof[4 * s_ + 4 + g];
+            const float b00 = smem[o0 + p0], b01 = smem[o0 + p1];
+            const float b10 = smem[o1 + p0], b11 = smem[o1 + p1];
+#pragma unroll
+            for (int t = 0; t < OT; ++t) {
+                const float a0 = wl[(s_ * OT + t) * 64 + lane];
+                acc0[t] = mma(a0, b00, acc0[t]);
+                acc1[t] = mma(a0, b01, acc1[t]);
+            }
+#pragma unroll
+            for (int t = 0; t < OT; ++t) {
+                const float a1 = wl[((s_ + 1) * OT + t) * 64 + lane];
+                acc0[t] = mma(a1, b10, acc0[t]);
+                acc1[t] = mma(a1, b11, acc1[t]);
+            }
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int tile = half ? pt1 : pt, n = tile * 16 + j;
+            if ((half && pt1 == pt) || n >= P) continue;
+#pragma unroll
+            for (int t = 0; t < OT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = t * 16 + 4 * g + r;
+                    if (o < d.Cout) {
+                        float v = (half ? acc1[t][r] : acc0[t][r]) + bv[t][r];
+                        if (relu) v = fmaxf(v, 0.0f);
+                        y[ybase + (size_t)o * d.OD * P + n] = v;
+                    }
+                }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------ forward, wide
 // For large outputs (the 721 x 1440 grids of BASELINE config 4b): a workgroup owns WIDE_TILES
 // consecutive 16-column tiles, each wave CPW of them for every channel tile, and the weights of a
@@ -1377,6 +1477,28 @@ extern "C" int wm_conv3d_fwd_f32(const float *x, const float *w, const float *b,
                                y, d, K, Ntot, relu);
         WM_LAUNCH_CHECK("conv3d_fwd_wide_kernel");
         return WM_OK;
+    }
+    {
+        // small volumes whose packed weights and input slab fit in LDS together: a workgroup per
+        // output plane, both operands from LDS
+        const int vsteps = (((K + 3) >> 2) + 1) & ~1, otk = ot == 3 ? 4 : ot;
+        const int PT = (d.OH * d.OW + 15) >> 4;
+        const size_t vlds = ((size_t)Cin * kD * H * W + (size_t)vsteps * otk * 64 + (size_t)vsteps * 4 +
+                             (size_t)PT * 16) * sizeof(float);
+        if (vlds <= RESIDENT_LDS && d.OW < ROWS_SEG && B * d.OD >= wm_num_cus() / 2 && PT >= WAVES) {
+            const int planes = B * d.OD;
+            if (otk == 1)
+                hipLaunchKernelGGL(conv3d_fwd_vol_kernel<1>, dim3(planes), dim3(BLOCK), vlds, st, x, w,
+                                   b, y, d, K, relu);
+            else if (otk == 2)
+                hipLaunchKernelGGL(conv3d_fwd_vol_kernel<2>, dim3(planes), dim3(BLOCK), vlds, st, x, w,
+                                   b, y, d, K, relu);
+            else
+                hipLaunchKernelGGL(conv3d_fwd_vol_kernel<4>, dim3(planes), dim3(BLOCK), vlds, st, x, w,
+                                   b, y, d, K, relu);
+            WM_LAUNCH_CHECK("conv3d_fwd_vol_kernel");
+            return WM_OK;
+        }
     }
     const int blocks = (Ntot + 15) / 16;            // one workgroup per 16-column tile
     // few tiles (the reference's second Conv3D layer has 90): eight waves split the contraction and
