@@ -712,6 +712,120 @@ extern "C" int wm_gram_f32(const float *X, const float *Y, int64_t n, int F, int
     return WM_OK;
 }
 
+namespace {
+
+// One wave, matrix in registers: lane i holds row i of the centred system (F <= 24, P <= 4).
+// The LDS kernel above spends its 20-27 us in ~3F barrier phases of float64 LDS round trips; here
+// an elimination step is two v_readlane per broadcast double (compile-time lane and register
+// indices: the loops are fully unrolled to WS_F with uniform guards) and one fused update per
+// element, with no barrier anywhere.  Same algorithm (right-looking Cholesky, rsqrt, forward and
+// back substitution); L goes through LDS once so that the back substitution can read a column.
+constexpr int WS_F = 24, WS_P = 4;
+
+__device__ __forceinline__ double readlane_f64(double v, int l)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+__global__ __launch_bounds__(64) void normal_solve_wave_kernel(const double *__restrict__ acc, int F,
+                                                               int P, int fit_intercept,
+                                                               double ridge,
+                                                               double *__restrict__ beta,
+                                                               int *__restrict__ status)
+{
+    __shared__ double Ls[WS_F][WS_F + 1];
+    const int lane = threadIdx.x, D = F + 1 + P;
+    const int i = lane < F ? lane : F - 1;               // clamped row for the loads
+    const double n = acc[(size_t)F * D + F];
+    const double inv_n = (fit_intercept && n > 0.0) ? 1.0 / n : 0.0;
+    bool bad = fit_intercept && !(n > 0.0);
+    const double si = acc[(size_t)i * D + F];
+    double a[WS_F], b[WS_P], T[WS_P];
+#pragma unroll
+    for (int p = 0; p < WS_P; ++p) {
+        T[p] = p < P ? acc[(size_t)F * D + F + 1 + p] : 0.0;
+        b[p] = p < P ? acc[(size_t)i * D + F + 1 + p] - si * T[p] * inv_n : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < WS_F; ++j) {
+        double v = 0.0;
+        if (j < F) {
+            v = acc[(size_t)i * D + j] - si * acc[(size_t)j * D + F] * inv_n;
+            if (j == lane) v += ridge;
+        }
+        a[j] = v;
+    }
+    double r[WS_F];                                       // 1 / L[k][k], wave-uniform
+#pragma unroll
+    for (int k = 0; k < WS_F; ++k) {
+        r[k] = 0.0;
+        if (k < F && !bad) {
+            const double dk = readlane_f64(a[k], k);
+            if (!(dk > 0.0)) {
+                bad = true;
+            } else {
+                const double rs = rsqrt(dk), inv = rs * rs;
+                r[k] = rs;
+                const double aik = a[k];                  // A[i][k]
+#pragma unroll
+                for (int j = k + 1; j < WS_F; ++j)
+                    if (j < F) a[j] -= aik * (readlane_f64(aik, j) * inv);   // rows i >= j matter
+                a[k] = aik * rs;                          // L[i][k]
+            }
+        }
+    }
+    double z[WS_P], bt[WS_P];
+#pragma unroll
+    for (int p = 0; p < WS_P; ++p) { z[p] = 0.0; bt[p] = 0.0; }
+    if (!bad) {
+        if (lane < F) {
+#pragma unroll
+            for (int j = 0; j < WS_F; ++j)
+                if (j < F) Ls[lane][j] = a[j];
+        }
+        // forward substitution L z = b: z_k lives in lane k
+#pragma unroll
+        for (int k = 0; k < WS_F; ++k)
+            if (k < F) {
+#pragma unroll
+                for (int p = 0; p < WS_P; ++p) {
+                    const double zk = readlane_f64(b[p], k) * r[k];
+                    if (lane == k) z[p] = zk;
+                    if (lane > k) b[p] -= a[k] * zk;
+                }
+            }
+        // back substitution L' beta = z: beta_k lives in lane k; lane i < k needs L[k][i]
+#pragma unroll
+        for (int k = WS_F - 1; k >= 0; --k)
+            if (k < F) {
+                const double lki = lane < k ? Ls[k][lane] : 0.0;
+#pragma unroll
+                for (int p = 0; p < WS_P; ++p) {
+                    const double bk = readlane_f64(z[p], k) * r[k];
+                    if (lane == k) bt[p] = bk;
+                    z[p] -= lki * bk;
+                }
+            }
+    }
+    const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+#pragma unroll
+    for (int p = 0; p < WS_P; ++p)
+        if (p < P) {
+            if (lane < F) beta[(size_t)lane * P + p] = bad ? qnan : bt[p];
+            double icpt = 0.0;
+            if (fit_intercept && !bad) {
+                const double part = lane < F ? si * inv_n * bt[p] : 0.0;
+                icpt = T[p] * inv_n - wave_sum(part);
+            }
+            if (lane == 0) beta[(size_t)F * P + p] = bad ? qnan : icpt;
+        }
+    if (lane == 0 && status) *status = bad ? 1 : 0;
+}
+
+}  // namespace
+
 extern "C" size_t wm_normal_solve_workspace_bytes(int F, int P)
 {
     if (F <= 0 || P <= 0) return 0;
@@ -728,6 +842,12 @@ extern "C" int wm_normal_solve_f64(const double *acc, int F, int P, int fit_inte
     WM_REQUIRE(ridge >= 0.0, WM_ERR_INVALID, "wm_normal_solve_f64: negative ridge");
     hipStream_t st = (hipStream_t)stream;
     const size_t bytes = (2 * ((size_t)F * F + (size_t)F * P) + 2 * (size_t)F + P) * sizeof(double);
+    if (F <= WS_F && P <= WS_P) {
+        hipLaunchKernelGGL(normal_solve_wave_kernel, dim3(1), dim3(64), 0, st, acc, F, P,
+                           fit_intercept, ridge, beta, status);
+        WM_LAUNCH_CHECK("normal_solve_wave_kernel");
+        return WM_OK;
+    }
     if (bytes <= SOLVE_LDS_LIMIT) {
         // per device: the attribute belongs to the function's image on the current device
         static bool attr_set_dev[64] = {};
