@@ -947,11 +947,8 @@ __host__ __device__ inline size_t wbr_lds_bytes(int rows, int ot)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src),    \
                                      (__attribute__((address_space(3))) void *)(dst), 16, 0, 0)
 
-#ifndef WBR_WAVES_ATTR
-#define WBR_WAVES_ATTR
-#endif
 template <int OT, int KTW>
-__global__ __launch_bounds__(BLOCK) WBR_WAVES_ATTR void conv3d_bwd_wb_rows_kernel(const float *__restrict__ x,
+__global__ __launch_bounds__(BLOCK) void conv3d_bwd_wb_rows_kernel(const float *__restrict__ x,
                                                                    const float *__restrict__ gy,
                                                                    double *__restrict__ partial,
                                                                    Dims3 d, int K, int ktiles)
