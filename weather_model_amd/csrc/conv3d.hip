@@ -521,6 +521,98 @@ __global__ __launch_bounds__(NW * 64) void conv3d_bwd_data_kernel(const float *_
     }
 }
 
+// ------------------------------------------------------------------------------ backward data, tap order
+// The split-K kernel above with the contraction re-ordered so that the weights come in 16-byte
+// pieces: within a 16-tap chunk of one output channel, MFMA step u takes taps 4g + u (g = lane
+// group), so lane (c, g) needs taps 4g..4g+3 of row (o, c) -- four CONSECUTIVE floats, one
+// dwordx4 load for four steps (16 lines per wave instruction instead of 64).  The kernel is bound
+// by its gathers (rocprof: 137 us for the 2.8 GFLOP of the reference's second layer).  Taps past
+// the end of a row read into the next row and meet gy = 0; only the last chunk of the very last
+// rows is loaded element-wise with a clamp.  NW waves take super-steps (o, chunk) round-robin.
+template <int CT, int NW>
+__global__ __launch_bounds__(NW * 64) void conv3d_bwd_data_tap_kernel(const float *__restrict__ gy,
+                                                                    const float *__restrict__ w,
+                                                                    float *__restrict__ gx, Dims3 d,
+                                                                    int Mtot)
+{
+    __shared__ int tab[KCHUNK + 16];
+    __shared__ float part[NW * CT * 256];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
+    const int k3 = d.kD * d.kH * d.kW, nch = (k3 + 15) >> 4;
+    const int S = d.OD * d.OH * d.OW, V = d.D * d.H * d.W;
+    const int tile = blockIdx.x;
+    int m = tile * 16 + j;
+    if (m >= Mtot) m = Mtot - 1;
+    const int b_ = m / V, pos = m % V;
+    const int pw = pos % d.W, ph = (pos / d.W) % d.H, pd = pos / (d.W * d.H);
+    const size_t gybase = (size_t)b_ * d.Cout * S;
+    const int pb = (pd * d.OH + ph) * d.OW + pw;
+    for (int k = tid; k < nch * 16; k += NW * 64) {
+        int e = -1;                                      // padding taps: never in range
+        if (k < k3) {
+            const int kw = k % d.kW, kh = (k / d.kW) % d.kH, kd = k / (d.kW * d.kH);
+            e = (kd << 16) | (kh << 8) | kw;
+        }
+        tab[k] = e;
+    }
+    __syncthreads();
+    f32x4 acc[CT];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nsup = d.Cout * nch;
+    const long long wtotal = (long long)d.Cout * d.Cin * k3;
+    for (int sp = wave; sp < nsup; sp += 2 * NW) {
+        float gv[2][4];
+        f32x4 wq[2][CT];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int ss = sp + h * NW;
+            const bool live = ss < nsup;                  // wave-uniform
+            const int sc = live ? ss : 0;
+            const int o = sc / nch, ch = sc - o * nch, tap0 = ch * 16 + 4 * g;
+#pragma unroll
+            for (int t = 0; t < CT; ++t) {
+                const int c = min(t * 16 + j, d.Cin - 1);
+                const long long wi = ((long long)o * d.Cin + c) * k3 + tap0;
+                if (o == d.Cout - 1 && ch == nch - 1) {  // the last rows' tail: stay inside w
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) wq[h][t][u] = w[wi + u < wtotal ? wi + u : wtotal - 1];
+                } else {
+                    wq[h][t] = *(const f4u *)(w + wi);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = tab[tap0 + u];
+                const int kd = (e >> 16) & 0xff, kh = (e >> 8) & 0xff, kw = e & 0xff;
+                const bool in = live && e >= 0 && (unsigned)(pd - kd) < (unsigned)d.OD &&
+                                (unsigned)(ph - kh) < (unsigned)d.OH &&
+                                (unsigned)(pw - kw) < (unsigned)d.OW;
+                // out-of-range taps read element 0 of this batch item's gy (in bounds) times zero
+                const int gi = in ? o * S + pb - ((kd * d.OH + kh) * d.OW + kw) : 0;
+                gv[h][u] = in ? gy[gybase + gi] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int t = 0; t < CT; ++t) acc[t] = mma(wq[h][t][u], gv[h][u], acc[t]);
+    }
+    reduce_tiles<CT>(part, acc, wave, lane);
+    for (int idx = tid; idx < CT * 256; idx += (NW * 64)) {
+        const int t = idx >> 8, l = (idx >> 2) & 63, r = idx & 3;
+        const int c = t * 16 + 4 * (l >> 4) + r;
+        const int mm = tile * 16 + (l & 15);
+        if (c >= d.Cin || mm >= Mtot) continue;
+        float v = 0.0f;
+#pragma unroll
+        for (int wv = 0; wv < NW; ++wv) v += part[((wv * CT + t) * 64 + l) * 4 + r];
+        gx[((size_t)(mm / V) * d.Cin + c) * V + mm % V] = v;
+    }
+}
+
 // ------------------------------------------------------------------------------ backward data, wide
 // Same decomposition as conv3d_fwd_wide_kernel for the input gradient of large tensors.
 template <int CT>
@@ -1570,7 +1662,14 @@ extern "C" int wm_conv3d_bwd_data_f32(const float *gy, const float *w, float *gx
     const int blocks = (Mtot + 15) / 16;            // one workgroup per 16-position tile
     const bool deep = blocks <= 4 * wm_num_cus();
 #define BWD_SPLITK(CT_)                                                                          \
-    if (deep)                                                                                    \
+    if (kD * kH * kW <= KCHUNK) {   /* contraction in tap order: 16-byte weight loads */        \
+        if (deep)                                                                                \
+            hipLaunchKernelGGL((conv3d_bwd_data_tap_kernel<CT_, 8>), dim3(blocks), dim3(512), 0, st, \
+                               gy, w, gx, d, Mtot);                                              \
+        else                                                                                     \
+            hipLaunchKernelGGL((conv3d_bwd_data_tap_kernel<CT_, 4>), dim3(blocks), dim3(256), 0, st, \
+                               gy, w, gx, d, Mtot);                                              \
+    } else if (deep)                                                                             \
         hipLaunchKernelGGL((conv3d_bwd_data_kernel<CT_, 8>), dim3(blocks), dim3(512), 0, st, gy, w, \
                            gx, d, K2, Mtot);                                                     \
     else                                                                                         \
