@@ -57,16 +57,22 @@ __device__ __forceinline__ void reduce_tiles(float *part, const f32x4 (&acc)[OT]
 }
 
 // ------------------------------------------------------------------------------ forward
-// One workgroup = one 16-column tile of outputs (all OT channel tiles); its four waves split the
-// contraction (wave w takes k-steps w, w+4, ...) and the partial tiles are summed through LDS in
-// a fixed order.  With one wave per tile the second layer of the reference ((16,16,7,7,14) ->
-// (16,64,3,3,10): only 90 column tiles, K = 2000) ran 23 workgroups of 500 dependent steps.
-template <int OT, int NW>   // OT 16-row tiles of output channels, NW waves splitting the contraction
-__global__ __launch_bounds__(NW * 64) void conv3d_fwd_kernel(const float *__restrict__ x,
-                                                           const float *__restrict__ w,
-                                                           const float *__restrict__ bias,
-                                                           float *__restrict__ y, Dims3 d, int K,
-                                                           int Ntot, int relu)
+// One workgroup = one 16-column tile of outputs (OT channel tiles; grid.y splits the channel tiles
+// when there are few column tiles); its NW waves split the contraction (16-tap super-steps, round
+// robin) and the partial tiles are summed through LDS in a fixed order.  With one wave per tile
+// the second layer of the reference ((16,16,7,7,14) -> (16,64,3,3,10): only 90 column tiles,
+// K = 2000) ran 23 workgroups of 500 dependent steps.  Inside a super-step MFMA step u takes taps
+// 4g + u (g = lane group), so lane (o, g) needs four CONSECUTIVE weights: one dwordx4 load for
+// four steps instead of four 16-line gathers -- the kernel is bound by its gathers (66 -> 42 us
+// with the channel tiles in grid.y, -> 20 us with the 16-byte weight loads).  Taps past K read
+// into the next row of w and meet x = 0; the chunk that holds the end of the rows is loaded
+// element-wise with a clamp.
+template <int OT, int NW>
+__global__ __launch_bounds__(NW * 64) void conv3d_fwd_tap_kernel(const float *__restrict__ x,
+                                                               const float *__restrict__ w,
+                                                               const float *__restrict__ bias,
+                                                               float *__restrict__ y, Dims3 d, int K,
+                                                               int Ntot, int relu)
 {
     __shared__ int off[KCHUNK];
     __shared__ float part[NW * OT * 256];
@@ -78,6 +84,7 @@ __global__ __launch_bounds__(NW * 64) void conv3d_fwd_kernel(const float *__rest
     const int b_ = n / S, sp = n % S;
     const int ow = sp % d.OW, oh = (sp / d.OW) % d.OH, od = sp / (d.OW * d.OH);
     const size_t nbase = (((size_t)b_ * d.Cin * d.D + od) * d.H + oh) * d.W + ow;
+    const long long wtotal = (long long)d.Cout * K;
 
     f32x4 acc[OT];
 #pragma unroll
@@ -85,30 +92,43 @@ __global__ __launch_bounds__(NW * 64) void conv3d_fwd_kernel(const float *__rest
 
     for (int kc = 0; kc < K; kc += KCHUNK) {
         const int kn = min(KCHUNK, K - kc);
-        const int kn4 = (kn + 3) & ~3;
+        const int nsup = (kn + 15) >> 4;                  // 16-tap super-steps of this chunk
         __syncthreads();
-        for (int k = tid; k < kn4; k += (NW * 64)) off[k] = k < kn ? tap_offset(d, kc + k) : 0;
+        for (int k = tid; k < nsup * 16; k += (NW * 64)) off[k] = k < kn ? tap_offset(d, kc + k) : -1;
         __syncthreads();
-        // UNR steps' operands are all requested before the first MFMA consumes one (hipcc does
-        // not unroll a loop around the MFMA builtin by itself, and one step = one L2 round trip)
-        for (int kb = 4 * wave; kb < kn4; kb += 4 * NW * UNR) {
-            float xv[UNR], wv[UNR][OT];
+        for (int s0 = wave; s0 < nsup; s0 += 2 * NW) {
+            float xv[2][4];
+            f32x4 wq[2][OT];
 #pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-                const int k = kb + u * 4 * NW + g;
-                const bool ok = k < kn;
-                const int kk = ok ? k : 0;
-                xv[u] = x[nbase + off[kk]];
+            for (int h = 0; h < 2; ++h) {
+                const int ss = s0 + h * NW;
+                const bool live = ss < nsup;              // wave-uniform
+                const int k0 = (live ? ss : 0) * 16 + 4 * g;
 #pragma unroll
                 for (int t = 0; t < OT; ++t) {
-                    const int o = (ot0 + t) * 16 + j;
-                    wv[u][t] = (ok && o < d.Cout) ? w[(size_t)o * K + kc + kk] : 0.0f;
+                    const int o = min((ot0 + t) * 16 + j, d.Cout - 1);
+                    const long long wi = (long long)o * K + kc + k0;
+                    if (kc + (live ? ss : 0) * 16 + 16 > K) {   // the chunk that holds the end of the rows
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) wq[h][t][u] = w[wi + u < wtotal ? wi + u : wtotal - 1];
+                    } else {
+                        wq[h][t] = *(const f4u *)(w + wi);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int o_ = off[k0 + u];
+                    const bool in = live && o_ >= 0;
+                    const float xl = x[nbase + (in ? o_ : 0)];
+                    xv[h][u] = in ? xl : 0.0f;
                 }
             }
 #pragma unroll
-            for (int u = 0; u < UNR; ++u)
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int t = 0; t < OT; ++t) acc[t] = mma(wv[u][t], xv[u], acc[t]);
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int t = 0; t < OT; ++t) acc[t] = mma(wq[h][t][u], xv[h][u], acc[t]);
         }
     }
     reduce_tiles<OT>(part, acc, wave, lane);
@@ -1595,16 +1615,16 @@ extern "C" int wm_conv3d_fwd_f32(const float *x, const float *w, const float *b,
     const bool deep = blocks <= 4 * wm_num_cus();
 #define FWD_SPLITK(OT_)                                                                          \
     if (deep)   /* one channel tile per workgroup: every workgroup gathers only its 16 rows of w */ \
-        hipLaunchKernelGGL((conv3d_fwd_kernel<1, 8>), dim3(blocks, ot), dim3(512), 0, st, x, w, b, y, \
-                           d, K, Ntot, relu);                                                    \
+        hipLaunchKernelGGL((conv3d_fwd_tap_kernel<1, 8>), dim3(blocks, ot), dim3(512), 0, st, x, w, b, \
+                           y, d, K, Ntot, relu);                                                 \
     else                                                                                         \
-        hipLaunchKernelGGL((conv3d_fwd_kernel<OT_, 4>), dim3(blocks), dim3(256), 0, st, x, w, b, y, \
-                           d, K, Ntot, relu)
+        hipLaunchKernelGGL((conv3d_fwd_tap_kernel<OT_, 4>), dim3(blocks), dim3(256), 0, st, x, w, b, \
+                           y, d, K, Ntot, relu)
     if (ot == 1) { FWD_SPLITK(1); }
     else if (ot == 2) { FWD_SPLITK(2); }
     else { FWD_SPLITK(4); }
 #undef FWD_SPLITK
-    WM_LAUNCH_CHECK("conv3d_fwd_kernel");
+    WM_LAUNCH_CHECK("conv3d_fwd_tap_kernel");
     return WM_OK;
 }
 
