@@ -57,6 +57,38 @@ def test_conv_full_grid_721x1440(conv_golden):
     assert relinf(gx[:, :, -8:, -8:], g["grid721/gx_br"]) < TOL
 
 
+def test_conv3x3_full_size_adjoint_identities_and_batch_independence():
+    """BASELINE config 3 at its full size, Conv2d(1 -> 1, 3x3) on (64,1,721,1440) (the flat stencil
+    kernels):  <A x, g> = <x, A^T g> = <w, dW(x, g)>,  db = sum g,  and every image of the batch
+    gives bit for bit what it gives alone (images are independent; the kernel's row ranges cross
+    image boundaries)."""
+    from weather_model_amd import ops
+    N, H, W = 64, 721, 1440
+    x = ops.synth_uniform((N, 1, H, W), seed=81)
+    w = ops.synth_uniform((1, 1, 3, 3), seed=82, lo=-1.0 / 3, hi=1.0 / 3)
+    b = ops.synth_uniform((1,), seed=83, lo=-1.0 / 3, hi=1.0 / 3)
+    g = ops.synth_uniform((N, 1, H - 2, W - 2), seed=84, lo=-1.0, hi=1.0)
+
+    def dot(a, c):
+        return float((a.double().flatten() * c.double().flatten()).sum())
+
+    y0 = ops.conv2d_forward(x, w, None)
+    lhs = dot(y0, g)
+    y = ops.conv2d_forward(x, w, b)
+    assert float((y - y0 - b.view(1, 1, 1, 1)).abs().max()) < 1e-6
+    for n in (0, 31, 63):
+        assert torch.equal(ops.conv2d_forward(x[n:n + 1].contiguous(), w, b), y[n:n + 1])
+    del y, y0
+    gx = ops.conv2d_backward_data(g, w, x.shape)
+    mid = dot(x, gx)
+    del gx
+    gw, gb = ops.conv2d_backward_wb(x, g, w.shape)
+    rhs = dot(w, gw)
+    scale = float((x.double() ** 2).sum().sqrt() * (g.double() ** 2).sum().sqrt()) / 3
+    assert abs(lhs - mid) < 5e-8 * scale and abs(lhs - rhs) < 5e-8 * scale, (lhs, mid, rhs, scale)
+    assert abs(float(gb.double()[0]) - float(g.double().sum())) < 1e-5 * float(g.double().abs().sum())
+
+
 def test_conv32_full_size_adjoint_identities():
     """BASELINE config 4b at its full size, Conv2d(32 -> 32, 3x3) on (8,32,721,1440): the three
     passes checked against each other through the identities every linear map and its adjoints
