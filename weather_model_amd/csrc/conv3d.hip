@@ -1032,14 +1032,21 @@ __global__ __launch_bounds__(BLOCK) void conv3d_bwd_wb_wide_kernel(const float *
 // above every B operand is a 16-tap x 4-position gather from global memory (sixteen scattered
 // 16-byte pieces per wave instruction, each x element fetched kH*kW times per workgroup); here a
 // workgroup's unit is 64 consecutive outputs of one output row, whose input window
-// (Cin*kD*kH rows of 68 floats: 64 + halo) and gy rows (Cout rows of 64 floats) are copied once
+// (Cin*kD*kH rows of 68 floats: 64 + halo) and gy rows (Cout rows of 64 floats) are copied
 // into LDS by 16-byte LDS-direct loads (global_load_lds_dwordx4: the LDS image is filled
 // linearly, one KiB per wave instruction, and each lane's SOURCE address picks the piece of the
 // row that belongs there, pitch padding included), and the MFMA operands are LDS reads at
-// immediate offsets of per-lane bases fixed for the whole kernel.  (Row-by-row dword copies of
-// the same tile were instruction-bound: 224 wave instructions per unit, 1.26 ms of a 2.5 ms
-// pass; this fill issues 36.)  Pitches (72 and 68 words) keep the 16 taps x 4 positions of a B
-// read and the 16 channels x 4 positions of an A read on distinct banks.  Accumulators stay in
+// immediate offsets of per-lane bases.  (Row-by-row dword copies of the same tile were
+// instruction-bound: 224 wave instructions per unit, 1.26 ms of a 2.5 ms pass.)
+// A workgroup walks DOWN a 64-column stripe, one output row per unit, and the window is a ring
+// over kH: input row ih lives in slot ih % kH, so a unit fetches only the Cin*kD rows of its
+// bottom input row (the others are still there from the units before); only the first unit of a
+// workgroup's run or of a stripe fills all kH slots.  That takes the fetches of this pass from
+// kH times x to once x; the time moved little (-4 %: per-workgroup clocks show the three resident
+// workgroups of a CU finishing at 1.46 / 1.55 / 1.62 ms whether a unit fetches 35 KB or 17 KB,
+// and four resident workgroups at 104 registers took the same total).
+// Pitches (72 and 68 words; slot stride = 16 mod 64) keep the 16 taps x 4 positions of a B read
+// and the 16 channels x 4 positions of an A read on distinct banks.  Accumulators stay in
 // registers across units and go to the workgroup's float64 slab every WBR_FLUSH units (1024
 // outputs), as in the wide kernel.
 constexpr int WBR_SEG = 64;        // outputs per unit
@@ -1047,12 +1054,19 @@ constexpr int WBR_XP = 72;         // x row pitch in LDS (words): 18 pieces of 1
 constexpr int WBR_XW = 68;         // x columns fetched per row (17 pieces): kW - 1 <= 4
 constexpr int WBR_GP = 68;         // gy row pitch (words): 17 pieces, = 4 mod 64
 constexpr int WBR_FLUSH = 16;
-constexpr int WBR_MAXX = 9;        // x pieces / 256 per thread  (Cin*kD*kH <= 128 rows)
+constexpr int WBR_MAXS = 5;        // x pieces / 256 per thread and slot  (Cin*kD <= 71 rows)
 constexpr int WBR_MAXG = 5;        // gy pieces / 256            (Cout <= 64)
 
-__host__ __device__ inline size_t wbr_lds_bytes(int rows, int ot)
+// words between two slots of the ring: Cin*kD rows, padded to 16 mod 64 banks
+__host__ __device__ inline int wbr_slot_stride(int cd)
 {
-    return ((size_t)rows * WBR_XP + (size_t)ot * 16 * WBR_GP + 2 * WBR_XP) * sizeof(float);
+    const int w = cd * WBR_XP;
+    return w + ((16 - w % 64) + 64) % 64;
+}
+
+__host__ __device__ inline size_t wbr_lds_bytes(int cd, int kH, int ot)
+{
+    return ((size_t)kH * wbr_slot_stride(cd) + (size_t)ot * 16 * WBR_GP + 2 * WBR_XP) * sizeof(float);
 }
 
 #define WM_GLDS16(src, dst)                                                                    \
@@ -1066,9 +1080,9 @@ __global__ __launch_bounds__(BLOCK) void conv3d_bwd_wb_rows_kernel(const float *
                                                                    Dims3 d, int K, int ktiles)
 {
     extern __shared__ __align__(16) float smem[];
-    const int rows = d.Cin * d.kD * d.kH;
-    // [rows][WBR_XP] x | [OT*16][WBR_GP] gy | [WBR_XP] ones | [WBR_XP] zeros
-    const int goff = rows * WBR_XP, ooff = goff + OT * 16 * WBR_GP, zoff = ooff + WBR_XP;
+    const int CD = d.Cin * d.kD, SS = wbr_slot_stride(CD);
+    // [kH slots][CD][WBR_XP] x | [OT*16][WBR_GP] gy | [WBR_XP] ones | [WBR_XP] zeros
+    const int goff = d.kH * SS, ooff = goff + OT * 16 * WBR_GP, zoff = ooff + WBR_XP;
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int S = d.OD * d.OH * d.OW;
@@ -1078,35 +1092,38 @@ __global__ __launch_bounds__(BLOCK) void conv3d_bwd_wb_rows_kernel(const float *
     for (int e = tid; e < OT * 16 * WBR_GP; e += BLOCK) smem[goff + e] = 0.0f;   // rows >= Cout stay zero
     for (int e = tid; e < WBR_XP; e += BLOCK) { smem[ooff + e] = 1.0f; smem[zoff + e] = 0.0f; }
 
-    // this lane's B-operand base (LDS word) of tap tile q: tap k = (wave + WAVES q) 16 + j
-    int koff[KTW];
+    // this lane's B operand of tap tile q: tap k = (wave + WAVES q) 16 + j = ((c kD + kd) kH + kh) kW + kw
+    // is at word  slot(oh + kh) SS + (c kD + kd) WBR_XP + kw  of the ring; kh = -1: a fixed row
+    int kbase[KTW], khq[KTW];
 #pragma unroll
     for (int q = 0; q < KTW; ++q) {
         const int k = (wave + WAVES * q) * 16 + j;
-        int o_ = zoff;
+        int o_ = zoff, kh_ = -1;
         if (k < K) {
-            const int kw = k % d.kW, r_ = k / d.kW;      // r_ = (c*kD + kd)*kH + kh: the LDS row
-            o_ = r_ * WBR_XP + kw;
+            const int kw = k % d.kW, r_ = k / d.kW;
+            kh_ = r_ % d.kH;
+            o_ = (r_ / d.kH) * WBR_XP + kw;
         } else if (k == K) {
             o_ = ooff;
         }
-        koff[q] = o_ + g;
+        kbase[q] = o_ + g;
+        khq[q] = kh_;
     }
     const int abase = goff + j * WBR_GP + g;
 
     // 16-byte pieces of the LDS image this thread fills, fixed for the kernel: piece P = tid +
-    // 256 i of the x part is row P / 18, columns 4 (P % 18).. (the 18th piece of a row is pitch
+    // 256 i of a slot is row P / 18, columns 4 (P % 18).. (the 18th piece of a row is pitch
     // padding and repeats the 17th); of the gy part row P / 17, columns 4 (P % 17).. (the 17th is
     // padding).  Element offsets from the unit's first column; -1 = nothing to fill.
-    const int nxs = (rows * 18 + BLOCK - 1) / BLOCK, ngs = (d.Cout * 17 + BLOCK - 1) / BLOCK;
-    int xsrc_off[WBR_MAXX], gsrc_off[WBR_MAXG];
+    const int nxs = (CD * 18 + BLOCK - 1) / BLOCK, ngs = (d.Cout * 17 + BLOCK - 1) / BLOCK;
+    int xsrc_off[WBR_MAXS], gsrc_off[WBR_MAXG];
 #pragma unroll
-    for (int i = 0; i < WBR_MAXX; ++i) {
+    for (int i = 0; i < WBR_MAXS; ++i) {
         const int P = tid + BLOCK * i, r_ = P / 18, pc = P - 18 * r_;
         int o_ = -1;
-        if (r_ < rows) {
-            const int kh = r_ % d.kH, t_ = r_ / d.kH, kd = t_ % d.kD, c = t_ / d.kD;
-            o_ = ((c * d.D + kd) * d.H + kh) * d.W + 4 * min(pc, 16);
+        if (r_ < CD) {
+            const int kd = r_ % d.kD, c = r_ / d.kD;
+            o_ = (c * d.D + kd) * d.H * d.W + 4 * min(pc, 16);
         }
         xsrc_off[i] = o_;
     }
@@ -1122,50 +1139,75 @@ __global__ __launch_bounds__(BLOCK) void conv3d_bwd_wb_rows_kernel(const float *
     for (int q = 0; q < KTW; ++q)
         voff[q] = 8u * (unsigned)((wave + WAVES * q) * 16 + j + 4 * g * (K + 1));
 
+    // units in (b, od, segment, oh) order: consecutive units are consecutive output rows of one
+    // 64-column stripe.  An XCD takes a contiguous eighth, each of its workgroups a contiguous run.
     const int segs = (d.OW + WBR_SEG - 1) / WBR_SEG;
     const int units = d.B * d.OD * d.OH * segs;
     const int upx = (units + 7) >> 3;
     const int xcd = blockIdx.x & 7, nslot = gridDim.x >> 3;
-    const int uend = min(units, (xcd + 1) * upx);
+    const int xfirst = xcd * upx, xn = max(0, min(units, xfirst + upx) - xfirst);
+    const int slot_ = (int)blockIdx.x >> 3;
+    const int ufirst = xfirst + (int)((long long)xn * slot_ / nslot);
+    const int uend = xfirst + (int)((long long)xn * (slot_ + 1) / nslot);
     const size_t xsample = (size_t)d.Cin * d.D * d.H * d.W, gsample = (size_t)d.Cout * S;
-    for (int ubase = xcd * upx + ((int)blockIdx.x >> 3); ubase < uend; ubase += nslot * WBR_FLUSH) {
+    int stripe = ufirst / d.OH, oh = ufirst - stripe * d.OH, ohm = oh % d.kH, seg = 0, od = 0, b_ = 0;
+    for (int ubase = ufirst; ubase < uend; ubase += WBR_FLUSH) {
     f32x4 acc[KTW][OT];
 #pragma unroll
     for (int q = 0; q < KTW; ++q)
 #pragma unroll
         for (int t = 0; t < OT; ++t) acc[q][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int ustop = min(uend, ubase + nslot * WBR_FLUSH);
-    for (int unit = ubase; unit < ustop; unit += nslot) {
-        const int row = unit / segs, seg = unit - row * segs;
+    const int ustop = min(uend, ubase + WBR_FLUSH);
+    for (int unit = ubase; unit < ustop; ++unit) {
+        if (unit != ufirst) {                              // next row of the stripe, or next stripe
+            ++oh;
+            if (++ohm == d.kH) ohm = 0;
+            if (oh == d.OH) { oh = 0; ohm = 0; ++stripe; }
+        }
+        // the shifted last segment of a row (an extra barrier per unit) comes FIRST among the
+        // stripes of an (image, plane): the workgroups that were dispatched first also get the
+        // larger share of the MFMA pipe (measured finish times of the three resident rounds:
+        // 1.46 / 1.55 / 1.62 ms), so the dearer units go to them
+        if (oh == 0 || unit == ufirst) {
+            const int sq = stripe % segs, q_ = stripe / segs;
+            seg = sq == 0 ? segs - 1 : sq - 1;
+            od = q_ % d.OD;
+            b_ = q_ / d.OD;
+        }
         // the last segment of a row is moved left to end at the row's end (the outputs it then
-        // shares with the segment before are masked out of gy), and its 68-column input window a
-        // little further so that it stays inside the row: B reads then start delta words in
+        // shares with the segment before are zeroed in the gy tile once it has landed), and its
+        // 68-column input window a little further so that it stays inside the row: B reads then
+        // start delta words in
         const int ow0 = min(seg * WBR_SEG, d.OW - WBR_SEG);
         const int xs0 = min(ow0, d.W - WBR_XW), delta = ow0 - xs0;
-        const int oh = row % d.OH, q_ = row / d.OH, od = q_ % d.OD, b_ = q_ / d.OD;
         const float *xsrc = x + (size_t)b_ * xsample + (size_t)((od * d.H + oh) * d.W + xs0);
         const float *gsrc = gy + (size_t)b_ * gsample + (size_t)((od * d.OH + oh) * d.OW + ow0);
         __syncthreads();                                   // every wave is past its reads of the tile
+        // input rows oh .. oh+kH-1: all of them at the top of a run or stripe, else the last
+        for (int kh = (unit == ufirst || oh == 0) ? 0 : d.kH - 1; kh < d.kH; ++kh) {
+            int sl = ohm + kh;
+            if (sl >= d.kH) sl -= d.kH;
+            const float *xr = xsrc + (size_t)kh * d.W;
+            float *dst = smem + sl * SS + 64 * wave * 4;
 #pragma unroll
-        for (int i = 0; i < WBR_MAXX; ++i)
-            if (i < nxs) {
-                if (xsrc_off[i] >= 0) WM_GLDS16(xsrc + xsrc_off[i], smem + (BLOCK * i + 64 * wave) * 4);
-            }
-        if (ow0 == seg * WBR_SEG) {
-#pragma unroll
-            for (int i = 0; i < WBR_MAXG; ++i)
-                if (i < ngs) {
-                    if (gsrc_off[i] >= 0)
-                        WM_GLDS16(gsrc + gsrc_off[i], smem + goff + (BLOCK * i + 64 * wave) * 4);
+            for (int i = 0; i < WBR_MAXS; ++i)
+                if (i < nxs) {
+                    if (xsrc_off[i] >= 0) WM_GLDS16(xr + xsrc_off[i], dst + BLOCK * i * 4);
                 }
-        } else {
-            for (int e = tid; e < d.Cout * WBR_SEG; e += BLOCK) {
-                const int o = e >> 6, n = e & 63;
-                const float v = gsrc[(size_t)o * S + n];
-                smem[goff + o * WBR_GP + n] = ow0 + n >= seg * WBR_SEG ? v : 0.0f;
-            }
         }
+#pragma unroll
+        for (int i = 0; i < WBR_MAXG; ++i)
+            if (i < ngs) {
+                if (gsrc_off[i] >= 0)
+                    WM_GLDS16(gsrc + gsrc_off[i], smem + goff + (BLOCK * i + 64 * wave) * 4);
+            }
         __syncthreads();                                   // vmcnt(0) + barrier: the tile has landed
+        if (ow0 != seg * WBR_SEG) {                        // one stripe in `segs`
+            const int m = seg * WBR_SEG - ow0;
+            for (int o = tid >> 2; o < d.Cout; o += BLOCK / 4)
+                for (int n = tid & 3; n < m; n += 4) smem[goff + o * WBR_GP + n] = 0.0f;
+            __syncthreads();
+        }
         // operands of step s+1 are read while the MFMAs of step s run; the barriers keep hipcc
         // from hoisting all 16 steps' LDS reads to the top (it did: 244 VGPRs)
 #define WBR_OPS(a_, b_, s_)                                                                  \
@@ -1177,7 +1219,11 @@ __global__ __launch_bounds__(BLOCK) void conv3d_bwd_wb_rows_kernel(const float *
         float a0[OT], b0[KTW], a1[OT], b1[KTW];
         int kofd[KTW];
 #pragma unroll
-        for (int q = 0; q < KTW; ++q) kofd[q] = koff[q] + delta;
+        for (int q = 0; q < KTW; ++q) {
+            int sl = khq[q] + ohm;
+            if (sl >= d.kH) sl -= d.kH;
+            kofd[q] = kbase[q] + delta + (khq[q] >= 0 ? sl * SS : 0);
+        }
         WBR_OPS(a0, b0, 0)
 #pragma unroll
         for (int s_ = 0; s_ < WBR_SEG / 4; s_ += 2) {
@@ -1496,8 +1542,8 @@ bool wb_rows_plan(int B, int Cin, int D, int H, int W, int Cout, int kD, int kH,
     const int K = Cin * kD * kH * kW;
     if (!wb_wide_shape(Ntot, K) || kW - 1 > WBR_XW - WBR_SEG || W < WBR_XW || OW < WBR_SEG) return false;
     const int otiles = (Cout + 15) / 16, ktiles = (K + 1 + 15) / 16;
-    const size_t bytes = wbr_lds_bytes(Cin * kD * kH, otiles == 3 ? 4 : otiles);
-    if (bytes > RESIDENT_LDS || Cin * kD * kH * 18 > BLOCK * WBR_MAXX) return false;
+    const size_t bytes = wbr_lds_bytes(Cin * kD, kH, otiles == 3 ? 4 : otiles);
+    if (bytes > RESIDENT_LDS || Cin * kD * 18 > BLOCK * WBR_MAXS) return false;
     const void *kfn = (const void *)wb_rows_kernel(otiles, (ktiles + WAVES - 1) / WAVES);
     if (bytes > 64 * 1024 &&
         hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
