@@ -126,7 +126,7 @@ class Conv3DModel:
             raise ValueError("optimizer must be 'adam' or a torch optimizer over model.params")
         self.optimizer = optimizer if isinstance(optimizer, torch.optim.Optimizer) else \
             torch.optim.Adam(list(self.params.values()), lr=1e-3, betas=(0.9, 0.999), eps=1e-7,
-                             capturable=True)
+                             capturable=True, fused=True)     # one multi-tensor kernel, not ten
         keys = []
         for m in list(metrics or []) + list(weighted_metrics or []):
             m = {"mean_absolute_error": "mae", "mean_squared_logarithmic_error": "msle"}.get(m, m)
