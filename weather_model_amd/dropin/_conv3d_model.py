@@ -191,7 +191,6 @@ class Conv3DModel:
             g = {"key": key, "x1": x1.clone(), "x2": x2.clone(), "y": y.clone()}
 
             def body():
-                self.optimizer.zero_grad(set_to_none=False)
                 pred = self.forward(g["x1"], g["x2"])
                 loss = self.loss_fn(pred, g["y"])
                 loss.backward()
@@ -207,11 +206,14 @@ class Conv3DModel:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                for p in plist:
-                    p.grad = torch.zeros_like(p)
                 for _ in range(2):
+                    self.optimizer.zero_grad(set_to_none=True)
                     body()
             torch.cuda.current_stream().wait_stream(side)
+            # no gradients exist at capture: backward then CREATES them in the graph's own pool
+            # (fixed addresses, rewritten by every replay) instead of zero-filling and adding
+            # into twelve existing ones -- two dozen tiny launches fewer per step
+            self.optimizer.zero_grad(set_to_none=True)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 g["loss"], g["pred"] = body()
