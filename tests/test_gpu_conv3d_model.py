@@ -114,15 +114,17 @@ def test_graphed_train_step_matches_eager():
     from weather_model_amd.dropin._conv3d_model import Conv3DModel
     a = Conv3DModel((1, 20, 20, 20), seed=5)
     b = Conv3DModel((1, 20, 20, 20), seed=5)
-    a.compile()
-    b.compile()
+    metrics = ["mean_absolute_error", "mean_squared_logarithmic_error"]
+    a.compile(loss="mean_squared_error", metrics=metrics)
+    b.compile(loss="mean_squared_error", metrics=metrics)
     rng = np.random.default_rng(1)
     batches = [(rng.uniform(size=(4, 1, 20, 20, 20)).astype(np.float32),
                 rng.uniform(size=(4, 1, 20, 20, 20)).astype(np.float32),
                 rng.uniform(size=(4, 1, 8000)).astype(np.float32)) for _ in range(3)]
-    la = [a.train_step(bt)["loss"] for bt in batches]
-    lb = [b.graphed_train_step(bt)["loss"] for bt in batches]
-    np.testing.assert_allclose(la, lb, rtol=1e-5)
+    la = [a.train_step(bt) for bt in batches]
+    lb = [b.graphed_train_step(bt) for bt in batches]
+    for key in ("loss", "mae", "msle"):                  # the metrics are computed inside the graph
+        np.testing.assert_allclose([l[key] for l in la], [l[key] for l in lb], rtol=1e-5)
     for k in a.params:
         assert relinf(b.params[k].detach().cpu().numpy(), a.params[k].detach().cpu().numpy()) < 1e-5, k
 

@@ -135,6 +135,7 @@ class Conv3DModel:
             keys.append(m)
         self._metric_keys = keys
         self.metrics_names = ["loss"] + keys
+        self.__dict__.pop("_graphs", None)                   # captured steps hold the old optimizer / metrics
 
     def _targets(self, y):
         t = y if isinstance(y, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(y, np.float32))
@@ -149,15 +150,20 @@ class Conv3DModel:
             return ((y - pred) ** 2).mean()
         return ((y.reshape(pred.shape[0], -1) - pred) ** 2).mean()
 
-    def _batch_metrics(self, pred, y):
-        out = {}
+    def _metric_tensors(self, pred, y):
+        """The compiled metrics of a batch as 0-d device tensors, in ``_metric_keys`` order."""
+        out = []
         yy = y if (y.dim() == 3 and self.broadcast_targets) else y.reshape(pred.shape[0], -1)
-        if "mae" in self._metric_keys:
-            out["mae"] = float((yy - pred).abs().mean())
-        if "msle" in self._metric_keys:
-            e = torch.log1p(pred.clamp_min(_MSLE_EPS)) - torch.log1p(yy.clamp_min(_MSLE_EPS))
-            out["msle"] = float((e * e).mean())
+        for key in self._metric_keys:
+            if key == "mae":
+                out.append((yy - pred).abs().mean())
+            else:                                            # msle
+                e = torch.log1p(pred.clamp_min(_MSLE_EPS)) - torch.log1p(yy.clamp_min(_MSLE_EPS))
+                out.append((e * e).mean())
         return out
+
+    def _batch_metrics(self, pred, y):
+        return {k: float(v) for k, v in zip(self._metric_keys, self._metric_tensors(pred, y))}
 
     def train_step(self, data):
         """One optimizer step on a batch (x1, x2, y) (convolution.py:46-62)."""
@@ -195,7 +201,10 @@ class Conv3DModel:
                 loss = self.loss_fn(pred, g["y"])
                 loss.backward()
                 self.optimizer.step()
-                return loss.detach(), pred.detach()
+                # loss and metrics leave the graph as ONE small tensor: one host read per step
+                with torch.no_grad():
+                    stats = torch.stack([loss.detach()] + self._metric_tensors(pred.detach(), g["y"]))
+                return stats, pred.detach()
 
             # warm up on a side stream (optimizer state, lazily initialised library state), with
             # the parameters and optimizer state restored afterwards
@@ -216,7 +225,7 @@ class Conv3DModel:
             self.optimizer.zero_grad(set_to_none=True)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                g["loss"], g["pred"] = body()
+                g["stats"], g["pred"] = body()
             # the graph holds the addresses of the parameters, their gradients and the Adam
             # moments: put the values back in place, never rebind the tensors
             with torch.no_grad():
@@ -234,10 +243,7 @@ class Conv3DModel:
         g["x2"].copy_(x2)
         g["y"].copy_(y)
         g["graph"].replay()
-        logs = {"loss": float(g["loss"])}
-        with torch.no_grad():
-            logs.update(self._batch_metrics(g["pred"], g["y"]))
-        return logs
+        return dict(zip(["loss"] + list(self._metric_keys), g["stats"].tolist()))
 
     def test_step(self, data):
         x1, x2, y = data
