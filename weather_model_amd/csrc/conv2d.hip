@@ -739,11 +739,13 @@ struct FlatPlan {
     unsigned rows_base, rows_rem;
 };
 
-// Row ranges are SHORT (2*RB - (kH-1) output rows, i.e. two full load batches) and one workgroup
+// Row ranges are SHORT (3*RB - (kH-1) output rows, i.e. three full load batches) and one workgroup
 // takes one range: the dispatcher hands ranges out in order, so at any moment the resident
 // workgroups work on one compact window of x and of y that slides through memory.  Measured on
 // 64 x 721 x 1440, (3,3): ranges that fill the chip once (36 rows each, every workgroup streaming
 // its own far-apart 200 KB) 114 us; 6-row ranges in order 100 us; pure copy (1,1) 110 -> 90 us.
+// Swept later: two / three / four / six batches per range 4.83 / 5.01 / 4.89 / 4.43 TB/s forward
+// (the halo rows are 33 / 20 / 14 / 9 % of the reads; longer ranges lose the compact window).
 // The halo rows two neighbouring ranges both read come out of L2 / Infinity Cache.
 template <typename K>
 bool flat_plan(K kernel, int N, int OH, int OW, int W, int kH, const void *x, const void *y,
@@ -758,7 +760,7 @@ bool flat_plan(K kernel, int N, int OH, int OW, int W, int kH, const void *x, co
     p->ring = ring;
     (void)kernel;
     const long long total_rows = (long long)N * OH;
-    int rows = 2 * RB - (kH - 1);
+    int rows = 3 * RB - (kH - 1);
     if (rows < RB) rows = RB;
     long long segs = (total_rows + rows - 1) / rows;
     // target_segs > 0 (backward, reads only: long ranges cost nothing and halve the halo): one
