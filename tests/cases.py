@@ -66,6 +66,7 @@ CONV3D_LARGE_CASES = [
     # three channel tiles x three tap tiles per wave: the weight gradient's float64 sums do not fit
     # in registers and take the slab path; depth of one (kD = 1 ring), shifted last segment
     ("rows_slab_sums", 3, 16, (1, 300, 1400), 40, (1, 3, 3), 44, 1),   # 1.25 M outputs
+    ("rows_kh1", 2, 16, (1, 500, 1400), 16, (1, 1, 3), 45, 1),         # a ring of one slot: every unit refills
     # small volumes (plane-resident weight gradient): the bias column alone in the last tap tile
     # (K = 16), three channel tiles, planes of 80 positions; and a plane that is not a multiple of 4
     ("vol_bias_tile", 2, 4, (3, 9, 11), 40, (1, 2, 2), 38, 1),
