@@ -71,6 +71,21 @@ int wm_conv2d_bwd_wb_f32(const float *x, const float *gy, float *gw, float *gb,
                          int N, int Cin, int H, int W, int Cout, int kH, int kW,
                          void *stream);
 
+/* No counterpart in the reference.  The same gradients as wm_conv2d_bwd_wb_f32 for callers that
+ * cannot allocate device memory (code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc): the float64 partial sums live in a static device array of
+ * WM_CONV2D_NOALLOC_SCRATCH_BYTES inside the library (one copy per GPU, held until the process
+ * ends) instead of a caller workspace.  Shapes whose partial sums do not fit
+ * (wm_conv2d_bwd_wb_workspace_bytes(...) > wm_conv2d_bwd_wb_noalloc_max_bytes()) are rejected
+ * with WM_ERR_UNSUPPORTED.  The call allocates and frees nothing.  Results are bitwise those of
+ * wm_conv2d_bwd_wb_f32.  All calls on one GPU share that GPU's array: calls that overlap on one
+ * GPU (different streams or threads) race -- serialise them. */
+#define WM_CONV2D_NOALLOC_SCRATCH_BYTES (1u << 20)
+size_t wm_conv2d_bwd_wb_noalloc_max_bytes(void);
+int wm_conv2d_bwd_wb_noalloc_f32(const float *x, const float *gy, float *gw, float *gb,
+                                 int N, int Cin, int H, int W, int Cout, int kH, int kW,
+                                 void *stream);
+
 /* 3-D counterpart: replaces keras.layers.Conv3D(filters, kernel_size, strides=1, padding='valid',
  * data_format='channels_first') forward (convolution.py:164,166,170,172) and, reached from
  * CustomModel.train_step's tape.gradient (convolution.py:49-54), its three gradients.

@@ -17,6 +17,8 @@
 // caller's workspace -> a fixed-order float64 finalize kernel (bitwise reproducible).
 #include "common.h"
 
+#include <mutex>
+
 namespace {
 
 constexpr int BLOCK = 256;
@@ -698,6 +700,31 @@ __global__ __launch_bounds__(BLOCK) void conv_bwd_wb_generic_kernel(
     }
 }
 
+// hipOccupancyMaxActiveBlocksPerMultiprocessor is a host-side query of a few microseconds and is
+// not legal under stream capture: ask once per (device, kernel, block size) and keep the answer.
+template <typename K>
+int cached_occupancy(K kernel, int block, int *out)
+{
+    struct Slot { const void *fn; int block; int occ; };
+    static std::mutex mu;
+    static Slot slots[64][48] = {};
+    int dev = 0;
+    WM_HIP(hipGetDevice(&dev));
+    WM_REQUIRE(dev >= 0 && dev < 64, WM_ERR_NO_DEVICE, "device index %d out of range", dev);
+    const void *fn = reinterpret_cast<const void *>(kernel);
+    std::lock_guard<std::mutex> lock(mu);
+    Slot *free_slot = nullptr;
+    for (Slot &s : slots[dev]) {
+        if (s.fn == fn && s.block == block) { *out = s.occ; return WM_OK; }
+        if (s.fn == nullptr && !free_slot) free_slot = &s;
+    }
+    int occ = 0;
+    WM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, block, 0));
+    if (free_slot) { free_slot->fn = fn; free_slot->block = block; free_slot->occ = occ; }
+    *out = occ;
+    return WM_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 struct StencilPlan {
     int strips, segs, blocks;
@@ -712,7 +739,7 @@ int stencil_plan(K kernel, int N, int OH, int OW, StencilPlan *p)
     const int cus = wm_num_cus();
     WM_REQUIRE(cus > 0, WM_ERR_NO_DEVICE, "no HIP device");
     int occ = 0;
-    WM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, BLOCK, 0));
+    if (int rc = cached_occupancy(kernel, BLOCK, &occ)) return rc;
     // The occupancy query over-reports only at the 8-blocks-per-CU end (SGPR-heavy kernels,
     // MI355X_MICROARCH residency note); a launch that is not fully resident would double the
     // kernel time, so never plan for more than 6 blocks per CU.
@@ -840,6 +867,33 @@ int bwd_wb_generic_splits(int N, int OH, int OW, int nent)
     return (int)s;
 }
 
+// ------------------------------------------------------------------------------------------
+// Scratch of the allocation-free entry point (wm_conv2d_bwd_wb_noalloc_f32): the float64
+// per-workgroup partial sums that wm_conv2d_bwd_wb_f32 keeps in the caller's workspace.  One copy
+// per GPU, held until the process ends.  The array's NAME is only a host-side handle; the device
+// address comes from hipGetSymbolAddress, once per device, and only that pointer is ever handed
+// to a kernel.
+constexpr size_t SCRATCH_BYTES = WM_CONV2D_NOALLOC_SCRATCH_BYTES;
+static __device__ __align__(256) unsigned char scratch[SCRATCH_BYTES];
+
+int scratch_ptr(void **out)
+{
+    static std::mutex mu;
+    static void *ptrs[64] = {};
+    int dev = 0;
+    WM_HIP(hipGetDevice(&dev));
+    WM_REQUIRE(dev >= 0 && dev < 64, WM_ERR_NO_DEVICE, "device index %d out of range", dev);
+    std::lock_guard<std::mutex> lock(mu);
+    if (!ptrs[dev]) {
+        void *p = nullptr;
+        WM_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        WM_REQUIRE(p != nullptr, WM_ERR_HIP, "hipGetSymbolAddress(scratch) returned a null address");
+        ptrs[dev] = p;
+    }
+    *out = ptrs[dev];
+    return WM_OK;
+}
+
 }  // namespace
 
 extern "C" int wm_conv2d_fwd_f32(const float *x, const float *w, const float *b, float *y, int N,
@@ -946,8 +1000,8 @@ extern "C" int wm_conv2d_bwd_wb_f32(const float *x, const float *gy, float *gw, 
     const int waves_ = (OW + WaveCols<KW_>::CW - 1) / WaveCols<KW_>::CW;                        \
     int occ = 0;                                                                                \
     if (KH_ * KW_ <= 9 && waves_ <= 16) {                                                       \
-        WM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(                                    \
-            &occ, conv_bwd_wb_c1f_kernel<KH_, KW_>, waves_ * 64, 0));                           \
+        if (int rc = cached_occupancy(conv_bwd_wb_c1f_kernel<KH_, KW_>, waves_ * 64, &occ))     \
+            return rc;                                                                          \
         if (occ * waves_ > 30) occ = 30 / waves_;                                               \
         if (occ > 6) occ = 6;                                                                   \
         if (occ < 1) occ = 1;                                                                   \
@@ -990,4 +1044,27 @@ extern "C" int wm_conv2d_bwd_wb_f32(const float *x, const float *gy, float *gw, 
                        nw, gw, gb);
     WM_LAUNCH_CHECK("reduce_partials_kernel");
     return WM_OK;
+}
+
+// No counterpart in the reference: the same weight/bias gradient for callers that cannot allocate
+// (HIP graph capture, tight serving loops).  The partial sums live in this library's static
+// device array instead of a caller workspace; every kernel of the path overwrites the part of it
+// that the finalize kernel reads, so nothing has to be cleared between calls.
+extern "C" size_t wm_conv2d_bwd_wb_noalloc_max_bytes(void) { return SCRATCH_BYTES; }
+
+extern "C" int wm_conv2d_bwd_wb_noalloc_f32(const float *x, const float *gy, float *gw, float *gb,
+                                            int N, int Cin, int H, int W, int Cout, int kH, int kW,
+                                            void *stream)
+{
+    WM_REQUIRE(x && gy && gw, WM_ERR_INVALID, "wm_conv2d_bwd_wb_noalloc_f32: null pointer");
+    if (int rc = check_dims(N, Cin, H, W, Cout, kH, kW)) return rc;
+    const size_t need = wm_conv2d_bwd_wb_workspace_bytes(N, Cin, H, W, Cout, kH, kW);
+    WM_REQUIRE(need > 0 && need <= SCRATCH_BYTES, WM_ERR_UNSUPPORTED,
+               "wm_conv2d_bwd_wb_noalloc_f32: this shape needs %zu bytes of partial sums, the "
+               "static scratch holds %zu -- use wm_conv2d_bwd_wb_f32 with a caller workspace",
+               need, SCRATCH_BYTES);
+    void *ptr = nullptr;
+    if (int rc = scratch_ptr(&ptr)) return rc;
+    return wm_conv2d_bwd_wb_f32(x, gy, gw, gb, ptr, SCRATCH_BYTES, N, Cin, H, W, Cout, kH, kW,
+                                stream);
 }
