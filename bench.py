@@ -47,10 +47,59 @@ def pmc_traffic(kernels, default_shape):
         return None
 
 
+def launch_ranks(ngpus, argv):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: this process (which has not
+    touched the GPU -- counting devices does not initialise HIP) starts N fresh child processes, one
+    per device, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, relays rank 0's JSON line and
+    exits with the worst child status.  Nothing is exec'ed from a process that has initialised HIP."""
+    import socket
+    import subprocess
+    rehearsal = bool(os.environ.get("WM_BENCH_REHEARSAL"))
+    ndev = torch.cuda.device_count()
+    if ndev < ngpus and not rehearsal:
+        raise SystemExit(f"bench.py --gpus {ngpus}: only {ndev} GPU(s) visible "
+                         f"(WM_BENCH_REHEARSAL=1 runs all ranks on GPU 0 over gloo)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(ngpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(ngpus),
+                   LOCAL_WORLD_SIZE=str(ngpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   WM_BENCH_LAUNCHER="self")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr,
+                                      stderr=sys.stderr, text=True))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode]
+    for q in procs[1:]:
+        try:
+            codes.append(q.wait(timeout=120))
+        except subprocess.TimeoutExpired:
+            q.kill()                      # exactly the PID this launcher started
+            codes.append(q.wait())
+    # rank 0's stdout may carry library chatter (gloo prints its connection line there): the JSON
+    # line goes to stdout alone, everything else to stderr
+    lines = out0.splitlines()
+    js = [k for k, ln in enumerate(lines) if ln.startswith("{") and ln.rstrip().endswith("}")]
+    for k, ln in enumerate(lines):
+        if not js or k != js[-1]:
+            print(ln, file=sys.stderr)
+    if js:
+        print(lines[js[-1]])
+    sys.stdout.flush()
+    bad = [c for c in codes if c != 0]
+    if bad:
+        raise SystemExit(f"bench.py launcher: rank exit codes {codes}")
+
+
 def dist_setup(ngpus):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    info = {"rccl_ranks": 1, "backend": None,
+            "launcher": os.environ.get("WM_BENCH_LAUNCHER",
+                                       "torchrun" if world > 1 else "single")}
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -58,17 +107,22 @@ def dist_setup(ngpus):
         # WM_BENCH_REHEARSAL=1: every rank on GPU 0 over gloo -- exercises the N > 1 code path on
         # a one-GPU box (numbers from such a run mean nothing)
         if os.environ.get("WM_BENCH_REHEARSAL"):
+            local = 0
             torch.cuda.set_device(0)
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-            return rank, world, 0
-        torch.cuda.set_device(local)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local))
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local))
+        info["rccl_ranks"] = dist.get_world_size()
+        info["backend"] = dist.get_backend()
+        if info["backend"] == "gloo":
+            info["rehearsal"] = "all ranks on GPU 0 over gloo: rates mean nothing"
     else:
         torch.cuda.set_device(0)
     if world != ngpus and rank == 0:
         print(f"[bench] note: --gpus {ngpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
-    return rank, world, local
+    return rank, world, local, info
 
 
 def barrier(world):
@@ -554,9 +608,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args.gpus, sys.argv[1:])
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (weather_model_amd has no CPU fallback)")
-    rank, world, _ = dist_setup(args.gpus)
+    rank, world, _, dinfo = dist_setup(args.gpus)
     cpu_base = not args.no_cpu_baseline
 
     out = {
@@ -564,7 +620,14 @@ def main():
         "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
+        "rccl_ranks": dinfo["rccl_ranks"], "backend": dinfo["backend"],
+        "launcher": dinfo["launcher"],
+        "parity": "conv2d / fused model / fields pinned by fixtures from the imported reference; "
+                  "regression and Conv3D parity unpinned (keras/tensorflow absent, oracle = "
+                  "closed form vs numpy lstsq / torch-CPU)",
     }
+    if "rehearsal" in dinfo:
+        out["rehearsal"] = dinfo["rehearsal"]
     if args.workload in ("all", "gram16", "gram64"):
         F = 64 if args.workload == "gram64" else 16
         rows = args.rows if F == 16 else min(args.rows, 25_000_000)
