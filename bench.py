@@ -56,7 +56,7 @@ def launch_ranks(ngpus, argv):
     import subprocess
     rehearsal = bool(os.environ.get("WM_BENCH_REHEARSAL"))
     ndev = torch.cuda.device_count()
-    if ndev < ngpus and not rehearsal:
+    if ndev < ngpus and not rehearsal and "plumbing" not in argv:
         raise SystemExit(f"bench.py --gpus {ngpus}: only {ndev} GPU(s) visible "
                          f"(WM_BENCH_REHEARSAL=1 runs all ranks on GPU 0 over gloo)")
     with socket.socket() as sk:
@@ -93,7 +93,7 @@ def launch_ranks(ngpus, argv):
         raise SystemExit(f"bench.py launcher: rank exit codes {codes}")
 
 
-def dist_setup(ngpus):
+def dist_setup(ngpus, cpu_only=False):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -106,7 +106,9 @@ def dist_setup(ngpus):
         os.environ.setdefault("MASTER_PORT", "29511")
         # WM_BENCH_REHEARSAL=1: every rank on GPU 0 over gloo -- exercises the N > 1 code path on
         # a one-GPU box (numbers from such a run mean nothing)
-        if os.environ.get("WM_BENCH_REHEARSAL"):
+        if cpu_only:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        elif os.environ.get("WM_BENCH_REHEARSAL"):
             local = 0
             torch.cuda.set_device(0)
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
@@ -116,9 +118,9 @@ def dist_setup(ngpus):
                                     device_id=torch.device("cuda", local))
         info["rccl_ranks"] = dist.get_world_size()
         info["backend"] = dist.get_backend()
-        if info["backend"] == "gloo":
+        if info["backend"] == "gloo" and not cpu_only:
             info["rehearsal"] = "all ranks on GPU 0 over gloo: rates mean nothing"
-    else:
+    elif not cpu_only:
         torch.cuda.set_device(0)
     if world != ngpus and rank == 0:
         print(f"[bench] note: --gpus {ngpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
@@ -141,17 +143,18 @@ def max_over_ranks(value, world):
     return float(t.item())
 
 
-def timed_steps(step, steps, warmup, world):
+def timed_steps(step, steps, warmup, world, cuda=True):
     """W untimed warm-ups, then exactly K steps between barrier+synchronize pairs."""
+    sync = torch.cuda.synchronize if cuda else (lambda: None)
     for i in range(warmup):
         step(i, False)
-    torch.cuda.synchronize()
+    sync()
     barrier(world)
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for i in range(steps):
         step(warmup + i, True)
-    torch.cuda.synchronize()
+    sync()
     barrier(world)
     t1 = time.perf_counter()
     return max_over_ranks(t1 - t0, world)
@@ -598,18 +601,60 @@ def run_fields(steps, warmup, rank, world, cpu_base):
     return res
 
 
+def run_plumbing(steps, warmup, rank, world, n_rows=1_000_000):
+    """BASELINE configs[0]: the 1-predictor fit of SURVEY 8d row 1 on the CPU numpy path (no GPU,
+    no libwm.so): every rank forms the float64 sums of its row shard, one gloo all-reduce, closed-form
+    slope/intercept.  It exercises the launcher, the row sharding and the exchange step only."""
+    rng = np.random.default_rng(1000 + rank)
+    x = rng.random(n_rows)
+    y = 0.7 * x + 0.2 + 0.01 * rng.standard_normal(n_rows)
+    beta = [None]
+
+    def step(i, timed):
+        acc = torch.tensor([n_rows, x.sum(), y.sum(), (x * x).sum(), (x * y).sum()],
+                           dtype=torch.float64)
+        if world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(acc)
+        n, sx, sy, sxx, sxy = acc.tolist()
+        slope = (sxy - sx * sy / n) / (sxx - sx * sx / n)
+        beta[0] = (slope, (sy - slope * sx) / n)
+
+    total = timed_steps(step, steps, warmup, world, cuda=False)
+    return {"value": n_rows * world * steps / total, "ms_per_step": total / steps * 1e3,
+            "slope": beta[0][0], "intercept": beta[0][1],
+            "planted_coef_max_err": max(abs(beta[0][0] - 0.7), abs(beta[0][1] - 0.2))}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="all", choices=["all", "gram16", "conv3x3", "gram64", "model32", "fields", "conv32", "conv3d_model"])
+    ap.add_argument("--workload", default="all", choices=["all", "gram16", "conv3x3", "gram64", "model32", "fields", "conv32", "conv3d_model",
+                             "plumbing"])
     ap.add_argument("--rows", type=int, default=100_000_000, help="rows per GPU (gram workloads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args.gpus, sys.argv[1:])
+    if args.workload == "plumbing":
+        rank, world, _, dinfo = dist_setup(args.gpus, cpu_only=True)
+        r = run_plumbing(args.steps, args.warmup, rank, world)
+        if rank == 0:
+            print(json.dumps({
+                "metric": "regression rows/s (1-predictor fit, CPU numpy plumbing)", "unit": "rows/s",
+                "n_gpus": 0, "n_ranks": world, "steps": args.steps, "warmup": args.warmup,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+                "data": "synthetic", "rccl_ranks": dinfo["rccl_ranks"], "backend": dinfo["backend"],
+                "launcher": dinfo["launcher"],
+                "config": {"workload": "singleRegression 1-predictor least squares, 1e6 rows per "
+                                       "rank, numpy float64 on the CPU (BASELINE configs[0])"}, **r}))
+        if world > 1:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (weather_model_amd has no CPU fallback)")
     rank, world, _, dinfo = dist_setup(args.gpus)
