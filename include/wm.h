@@ -173,10 +173,12 @@ int    wm_model_train_f32(const float *params, const float *x, const float *y, c
                           size_t workspace_bytes, int64_t B, int64_t B_global, void *stream);
 
 /* torch.optim.Adam step with the reference's defaults semantics (newConvolution.py:185,225):
- * no weight decay, no amsgrad; step counts from 1; grads are multiplied by grad_scale first. */
+ * no weight decay, no amsgrad; step counts from 1; grads are multiplied by grad_scale first.
+ * lr, betas and eps are doubles, as torch holds them: the bias corrections 1 - beta^step and the
+ * step size lr / (1 - beta1^step) are formed in double and rounded to float once. */
 int    wm_adam_step_f32(float *params, const float *grads, float *m, float *v, int64_t count,
-                        int step, float lr, float beta1, float beta2, float eps, float grad_scale,
-                        void *stream);
+                        int step, double lr, double beta1, double beta2, double eps,
+                        float grad_scale, void *stream);
 
 /* ------------------------------------------------------------------ fields (8f next rows) */
 

@@ -101,17 +101,52 @@ def test_adam_steps_match_reference(model_golden):
     v = torch.zeros_like(p)
     x = torch.from_numpy(g["x"][:, 0]).cuda()
     y = torch.from_numpy(g["y"][:, 0]).cuda()
+    p0 = _flat(sd).astype(np.float64)
+    prev = p0
     for step in range(3):
         _, _, grads = ops.model_train(p, x[step:step + 1], y=y[step:step + 1])
         ops.adam_step(p, grads, m, v, step + 1)
-        ref = _flat(_sd(g, f"adam{step + 1}/"))
-        assert np.abs(p.cpu().numpy() - ref).max() < 2e-5, step
+        ref = _flat(_sd(g, f"adam{step + 1}/")).astype(np.float64)
+        # the UPDATE of this step, not the parameter: a parameter moves ~1e-3 per step, so an
+        # absolute bound on p would let a 2 % error in the update through
+        _assert_update(p.cpu().numpy().astype(np.float64) - prev, ref - prev, step)
+        prev = ref
+        # continue from the reference's parameters so that every step is checked on its own
+        p.copy_(torch.from_numpy(_flat(_sd(g, f"adam{step + 1}/"))))
     # batched step (mean gradient over 8 samples)
     p = torch.from_numpy(_flat(sd)).cuda()
     m.zero_(); v.zero_()
     _, _, grads = ops.model_train(p, x[:8], y=y[:8])
     ops.adam_step(p, grads, m, v, 1)
-    assert np.abs(p.cpu().numpy() - _flat(_sd(g, "adam_b8/"))).max() < 2e-5
+    du = p.cpu().numpy().astype(np.float64) - p0
+    dref = _flat(_sd(g, "adam_b8/")).astype(np.float64) - p0
+    # (a) the Adam kernel itself: float64 Adam applied to OUR gradient reproduces the update
+    gd = grads.cpu().numpy().astype(np.float64)
+    lr, eps = 1e-3, 1e-8
+    exact = -lr * gd / (np.abs(gd) + eps)          # step 1: m_hat = g, sqrt(v_hat) = |g|
+    assert np.abs(du - exact).max() <= 1e-4 * lr
+    # (b) against the reference's batched step.  At step 1 the update is lr * g / (|g| + eps): for
+    # the few dozen weights whose mean gradient is within ~100 eps of zero it amplifies a gradient
+    # difference dg by eps / (|g| + eps)^2.  The gradient itself is held to 1e-5 * ||g||_inf (the
+    # conv tolerance), so an element's update is held to 1e-4 * lr plus what that dg can do to it;
+    # for every weight with |g| >= 1e-5 that is 1.1e-4 * lr.
+    dg = 1e-5 * np.abs(gd).max()
+    bound = 1e-4 * lr + lr * eps * dg / (np.abs(gd) + eps) ** 2
+    assert (np.abs(du - dref) <= bound).all(), float((np.abs(du - dref) / bound).max())
+    strong = np.abs(gd) >= 1e-5
+    assert strong.sum() > 10000
+    assert np.abs(du - dref)[strong].max() <= 1.1e-4 * lr
+
+
+def _assert_update(du, dref, tag):
+    """Relative error of an Adam update, ||du - dref||_inf / ||dref||_inf <= 1e-4.  The stored
+    reference parameters are float32, so a difference of two of them carries up to one ulp of the
+    PARAMETER (6e-8 * |p| ~ 2e-8 for |p| ~ 0.3), i.e. ~2e-5 of a 1e-3 update: 1e-4 leaves room for
+    that and nothing else."""
+    scale = np.abs(dref).max()
+    assert scale > 1e-4, (tag, scale)          # Adam moves parameters by ~lr = 1e-3 per step
+    err = np.abs(du - dref).max() / scale
+    assert err <= 1e-4, (tag, err, int(np.abs(du - dref).argmax()))
 
 
 def test_large_batch_properties():
@@ -158,8 +193,15 @@ def test_dropin_module_reproduces_reference_training(model_golden):
     data = [(x[i], y[i]) for i in range(3)]
     nc.training_loop(data, model, loss_fn, opt, 3, 0)
     ref = {k[6:]: g[k] for k in g.files if k.startswith("adam3/")}
+    # three steps chained: relative error of the total movement p3 - p0 of every tensor against
+    # the reference's (movements are ~3e-3; a tensor the model never touches must not move at all)
     for k, v in model.state_dict().items():
-        assert np.abs(v.cpu().numpy() - ref[k]).max() < 2e-5, k
+        moved = ref[k].astype(np.float64) - sd[k].numpy().astype(np.float64)
+        ours = v.cpu().numpy().astype(np.float64) - sd[k].numpy().astype(np.float64)
+        if np.abs(moved).max() == 0.0:
+            assert np.abs(ours).max() == 0.0, k
+        else:
+            assert np.abs(ours - moved).max() <= 2e-3 * np.abs(moved).max(), k
     correct, total, _ = nc.testing_loop([(x[i], y[i]) for i in range(8)], model, loss_fn)
     assert total == 8 and 0 <= correct <= 8
 

@@ -120,3 +120,33 @@ def test_synth_is_counter_based():
     assert a.min() >= 0.0 and a.max() < 1.0
     g = synth.normal(6, (200000,))
     assert abs(g.mean()) < 0.01 and abs(g.std() - 1.0) < 0.01
+
+
+def test_eager_torch_restatement_matches_reference(model_golden):
+    """oracle/model_torch.py (bench.py's library CPU baseline for the model) against the reference's
+    own run: outputs, per-sample gradients and three Adam steps.  Same library, same float32
+    arithmetic, same operation order -> agreement at rounding level."""
+    import torch
+    from oracle import model_torch
+    g = model_golden
+    sd = _sd(g)
+    torch.manual_seed(0)
+    m = model_torch.EagerModel(sd)
+    x = torch.from_numpy(g["x"])
+    y = torch.from_numpy(g["y"])
+    with torch.no_grad():
+        out = torch.cat([m(x[i]) for i in range(8)]).numpy()
+    assert relinf(out, g["out"][:8]) < 1e-6
+    for i in range(2):
+        m.zero_grad()
+        torch.nn.functional.mse_loss(m(x[i]), y[i]).backward()
+        for n in model_torch.PARAM_NAMES:
+            assert relinf(m.get(n).grad.numpy(), g["grad4/" + n][i]) < 2e-6, n
+    m.zero_grad()
+    losses = model_torch.train_steps(m, x[:3], y[:3])
+    assert np.allclose(losses[0], g["loss"][0], rtol=1e-5)
+    ref = _sd(g, "adam3/")
+    for n in model_torch.PARAM_NAMES:
+        moved = ref[n].astype(np.float64) - sd[n].astype(np.float64)
+        ours = m.get(n).detach().numpy().astype(np.float64) - sd[n].astype(np.float64)
+        assert np.abs(ours - moved).max() <= 1e-3 * max(np.abs(moved).max(), 1e-12), n

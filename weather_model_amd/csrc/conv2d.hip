@@ -47,6 +47,34 @@ constexpr int BLOCK = 256;
 #define WM_STENCIL_BPC 6
 #endif
 constexpr int RB = WM_STENCIL_RB;
+// forward flat kernel: load batches per range, consecutive ranges per XCD, minimum dynamic LDS per
+// workgroup (an occupancy cap: 160 KB per CU / this)
+#ifndef WM_FWD_RB
+#define WM_FWD_RB 2
+#endif
+constexpr int FRB = WM_FWD_RB;      // rows per load batch of the flat forward kernel
+#ifndef WM_FWD_BATCHES
+#define WM_FWD_BATCHES 3
+#endif
+#ifndef WM_FWD_XCD_RUN
+#define WM_FWD_XCD_RUN 8
+#endif
+#ifndef WM_FWD_LDS_MIN
+#define WM_FWD_LDS_MIN 0
+#endif
+// probe builds (tools/probe/conv_variants.py, -DWM_PROBE_ENV) read the knobs from the environment
+// at every call; the product build compiles them in
+#ifdef WM_PROBE_ENV
+#include <stdlib.h>
+static int wm_knob(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+#define WM_KNOB(name) wm_knob(#name, name)
+#else
+#define WM_KNOB(name) (name)
+#endif
 
 struct RowWalk {
     int steps;           // input rows this thread streams
@@ -274,12 +302,24 @@ template <int KH, int KW>
 __global__ __launch_bounds__(1024) void conv_fwd_c1f_kernel(
     const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ b,
     float *__restrict__ y, int H, int W, int OH, int OW, unsigned rows_base, unsigned rows_rem,
-    int relu, int ring_mask)
+    int relu, int ring_mask, int xcd_run)
 {
     extern __shared__ __attribute__((aligned(16))) float ring[];
     constexpr int EXT = 4 + KW - 1;
     const int lane = threadIdx.x & 63, wq = threadIdx.x >> 6;
-    const unsigned seg = blockIdx.x;
+    // Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one L2).  Inside every
+    // run of 8*XS workgroups, XCD x takes the XS CONSECUTIVE ranges x*XS .. x*XS+XS-1, so the
+    // KH-1 input rows two neighbouring ranges share are read twice through the SAME L2 (the
+    // mapping is speed only: any placement gives the same result).
+    unsigned seg = blockIdx.x;
+    if (xcd_run > 0) {
+        const unsigned run = 8u * (unsigned)xcd_run;
+        const unsigned base = seg / run * run;
+        if (base + run <= gridDim.x) {
+            const unsigned within = seg - base;
+            seg = base + (within & 7u) * (unsigned)xcd_run + (within >> 3);
+        }
+    }
     const unsigned r0 = seg * rows_base + min(seg, rows_rem);
     const unsigned cnt = rows_base + (seg < rows_rem ? 1u : 0u);
     const unsigned n0 = r0 / (unsigned)OH, i0 = r0 - n0 * (unsigned)OH;
@@ -317,24 +357,38 @@ __global__ __launch_bounds__(1024) void conv_fwd_c1f_kernel(
     // the loads of batch k+1 are in flight while batch k is consumed and flushed (the barriers of
     // the flush would otherwise leave the memory pipe idle); the last batch re-reads its own rows
     // instead of branching around the loads
-    const int nfull = steps / RB;
-    f32x4 cur[RB], nxt[RB];
-    if (nfull > 0) load_rows_f<KH, KW, RB>(cur, xq, W);
-    for (int bi = 0; bi < nfull; ++bi) {
-        const float *__restrict__ xn = xq + (bi + 1 < nfull ? (size_t)RB * W : (size_t)0);
-        load_rows_f<KH, KW, RB>(nxt, xn, W);
-        xq += (size_t)RB * W;
+    // The last KH-1 input rows of this range are the first rows of the next range, which its
+    // workgroup (same XCD, dispatched a moment later) loads at the START of its life.  They are
+    // loaded here first as well and kept in registers until the end: both reads then fall within
+    // microseconds of each other and one of them is an L2 hit instead of a second trip through the
+    // fabric 10 us later (PMC: 1.28x the algorithmic read traffic before).
+    constexpr int TR = KH - 1;
+    f32x4 tail[TR > 0 ? TR : 1];
+    if constexpr (TR > 0) {
+        load_rows_f<KH, KW, TR>(tail, xq + (size_t)(steps - TR) * W, W);
         __builtin_amdgcn_sched_barrier(0);
-        fwd_batch_f<KH, KW, RB>(cur, ring, fo, win, wr, bias, relu, j0, nst, h, hmin, H, OW);
-#pragma unroll
-        for (int u = 0; u < RB; ++u) cur[u] = nxt[u];
     }
-    for (int s = nfull * RB; s < steps; ++s) {
+    const int main_steps = steps - TR;
+    const int nfull = main_steps / FRB;
+    f32x4 cur[FRB], nxt[FRB];
+    if (nfull > 0) load_rows_f<KH, KW, FRB>(cur, xq, W);
+    for (int bi = 0; bi < nfull; ++bi) {
+        const float *__restrict__ xn = xq + (bi + 1 < nfull ? (size_t)FRB * W : (size_t)0);
+        load_rows_f<KH, KW, FRB>(nxt, xn, W);
+        xq += (size_t)FRB * W;
+        __builtin_amdgcn_sched_barrier(0);
+        fwd_batch_f<KH, KW, FRB>(cur, ring, fo, win, wr, bias, relu, j0, nst, h, hmin, H, OW);
+#pragma unroll
+        for (int u = 0; u < FRB; ++u) cur[u] = nxt[u];
+    }
+    for (int s = nfull * FRB; s < main_steps; ++s) {
         f32x4 one[1];
         load_rows_f<KH, KW, 1>(one, xq, W);
         xq += W;
         fwd_batch_f<KH, KW, 1>(one, ring, fo, win, wr, bias, relu, j0, nst, h, hmin, H, OW);
     }
+    if constexpr (TR > 0)
+        fwd_batch_f<KH, KW, TR>(tail, ring, fo, win, wr, bias, relu, j0, nst, h, hmin, H, OW);
 }
 
 template <int KH, int KW, int NB>
@@ -561,6 +615,181 @@ __global__ __launch_bounds__(1024) void conv_bwd_wb_c1f_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// Backward-data, flat stencil variant (Cin = Cout = 1, W % 4 == 0): gx = full correlation of gy with
+// the flipped kernel,  gx[n,p,q] = sum_{kh,kw} w[kh,kw] gy[n,p-kh,q-kw]  (gy = 0 outside).
+// Same decomposition as conv_fwd_c1f_kernel -- a workgroup spans the row and owns one short range
+// of the N*H output rows, ranges handed out in order with XCD-local runs, the KH-1 gy rows a range
+// shares with its successor loaded first and kept in registers -- but the roles of the two tensors
+// are swapped: the OUTPUT rows (W floats) are 16-byte aligned, so a lane stores its four columns
+// directly (a wave stores one aligned KiB, no LDS ring, no barrier), and the INPUT rows (OW floats)
+// start at any dword, which loads do not mind.  A lane loads its own four gy columns (16 B) plus
+// the two columns to their left (8 B) per row.
+// Rows are walked in a virtual padded space: every image has H rows, of which rows >= OH are the
+// zero padding below it -- which is also the zero padding above the next image, so the register
+// window needs no reset at an image boundary.
+struct GyRow {
+    f4u own;
+    f2u halo;
+    bool valid;
+};
+
+// virtual row v -> row in image p (negative above image 0) and flat gy row gr of the next valid row
+__device__ __forceinline__ void virtual_row(long long v, int H, int OH, int &p, unsigned &gr)
+{
+    if (v >= 0) {
+        const unsigned n = (unsigned)v / (unsigned)H;
+        p = (int)((unsigned)v - n * (unsigned)H);
+        gr = n * (unsigned)OH + (unsigned)min(p, OH);
+    } else {
+        p = (int)v;
+        gr = 0;
+    }
+}
+
+template <int NB>
+__device__ __forceinline__ void load_gy_rows(GyRow (&rows)[NB], const float *__restrict__ gy,
+                                             int OW, int OH, int H, unsigned last_row, int jg,
+                                             int jh, int &p, unsigned &gr)
+{
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        const bool valid = p >= 0 && p < OH;
+        const size_t row = (size_t)min(gr, last_row) * OW;     // always in bounds; zeroed if !valid
+        rows[u].own = *reinterpret_cast<const f4u *>(gy + row + jg);
+        rows[u].halo = *reinterpret_cast<const f2u *>(gy + row + jh);
+        rows[u].valid = valid;
+        gr += valid ? 1u : 0u;
+        p = (p + 1 == H) ? 0 : p + 1;
+    }
+}
+
+template <int KH, int KW, int NB>
+__device__ __forceinline__ void bwd_data_batch(const GyRow (&rows)[NB], float *__restrict__ &gq,
+                                               float (&win)[KH][4 + KW - 1],
+                                               const float (&wr)[KH][KW], int shift, bool has_halo,
+                                               bool active, int &skip, int W)
+{
+    constexpr int EXT = 4 + KW - 1;
+    constexpr int HO = KW - 1 <= 2 ? 2 - (KW - 1) : 0;     // first halo column used of the two loaded
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+#pragma unroll
+        for (int kh = 0; kh < KH - 1; ++kh)
+#pragma unroll
+            for (int e = 0; e < EXT; ++e) win[kh][e] = win[kh + 1][e];
+        const float l0 = rows[u].own.x, l1 = rows[u].own.y, l2 = rows[u].own.z, l3 = rows[u].own.w;
+        float g[4];
+        g[0] = shift == 0 ? l0 : (shift == 1 ? l1 : (shift == 2 ? l2 : l3));
+        g[1] = shift == 0 ? l1 : (shift == 1 ? l2 : (shift == 2 ? l3 : 0.0f));
+        g[2] = shift == 0 ? l2 : (shift == 1 ? l3 : 0.0f);
+        g[3] = shift == 0 ? l3 : 0.0f;
+        const bool v = rows[u].valid;
+        const float hl[2] = {rows[u].halo.x, rows[u].halo.y};
+#pragma unroll
+        for (int e = 0; e < KW - 1; ++e)
+            win[KH - 1][e] = (v && has_halo) ? hl[(HO + e) & 1] : 0.0f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) win[KH - 1][KW - 1 + e] = v ? g[e] : 0.0f;
+        if (skip > 0) {
+            --skip;                     // window refill: the first KH-1 rows of a range
+        } else {
+            f32x4 out;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int i = 0; i < KH; ++i)
+#pragma unroll
+                    for (int kw = 0; kw < KW; ++kw)
+                        acc = fmaf(wr[KH - 1 - i][kw], win[i][e + (KW - 1) - kw], acc);
+                out[e] = acc;
+            }
+            if (active) __builtin_nontemporal_store(out, reinterpret_cast<f32x4 *>(gq));
+            gq += W;
+        }
+    }
+}
+
+template <int KH, int KW>
+__global__ __launch_bounds__(1024) void conv_bwd_data_c1f_kernel(
+    const float *__restrict__ gy, const float *__restrict__ w, float *__restrict__ gx, int H,
+    int W, int OH, int OW, unsigned last_row, unsigned rows_base, unsigned rows_rem, int xcd_run)
+{
+    constexpr int EXT = 4 + KW - 1;
+    constexpr int TR = KH - 1;
+    unsigned seg = blockIdx.x;
+    if (xcd_run > 0) {                              // XCD-local runs: see conv_fwd_c1f_kernel
+        const unsigned run = 8u * (unsigned)xcd_run;
+        const unsigned base = seg / run * run;
+        if (base + run <= gridDim.x) {
+            const unsigned within = seg - base;
+            seg = base + (within & 7u) * (unsigned)xcd_run + (within >> 3);
+        }
+    }
+    const unsigned r0 = seg * rows_base + min(seg, rows_rem);      // first of the N*H output rows
+    const unsigned cnt = rows_base + (seg < rows_rem ? 1u : 0u);
+    const int j0 = 4 * (int)threadIdx.x;
+    const bool active = j0 < W;
+    const int jc = min(j0, W - 4);
+    const int jg = min(jc, OW - 4), shift = jc - jg;
+    const bool has_halo = jc >= 2;
+    const int jh = max(jc - 2, 0);
+
+    float wr[KH][KW];
+#pragma unroll
+    for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < KW; ++kw) wr[kh][kw] = w[kh * KW + kw];
+
+    // virtual row (H rows per image) of the first gy row this range needs; negative above image 0
+    const long long v0 = (long long)r0 - TR;
+    int p;
+    unsigned gr;
+    virtual_row(v0, H, OH, p, gr);
+    const int steps = (int)cnt + TR;
+    float *__restrict__ gq = gx + (size_t)r0 * W + jc;
+    float win[KH][EXT];
+#pragma unroll
+    for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+        for (int e = 0; e < EXT; ++e) win[kh][e] = 0.0f;
+    int skip = TR;
+
+    // the last KH-1 gy rows first (they are the first rows of the next range: same XCD, same time)
+    GyRow tail[TR > 0 ? TR : 1];
+    if constexpr (TR > 0) {
+        int pt;
+        unsigned grt;
+        virtual_row(v0 + steps - TR, H, OH, pt, grt);
+        load_gy_rows<TR>(tail, gy, OW, OH, H, last_row, jg, jh, pt, grt);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const int main_steps = steps - TR;
+    const int nfull = main_steps / FRB;
+    GyRow cur[FRB], nxt[FRB];
+    if (nfull > 0) load_gy_rows<FRB>(cur, gy, OW, OH, H, last_row, jg, jh, p, gr);
+    for (int bi = 0; bi < nfull; ++bi) {
+        // the batch after the last full one is loaded too (always in bounds) and either feeds the
+        // single-row steps below or is dropped
+        int pn = p;
+        unsigned grn = gr;
+        load_gy_rows<FRB>(nxt, gy, OW, OH, H, last_row, jg, jh, pn, grn);
+        if (bi + 1 < nfull) { p = pn; gr = grn; }
+        __builtin_amdgcn_sched_barrier(0);
+        bwd_data_batch<KH, KW, FRB>(cur, gq, win, wr, shift, has_halo, active, skip, W);
+#pragma unroll
+        for (int u = 0; u < FRB; ++u) cur[u] = nxt[u];
+    }
+    for (int s = nfull * FRB; s < main_steps; ++s) {
+        GyRow one[1];
+        load_gy_rows<1>(one, gy, OW, OH, H, last_row, jg, jh, p, gr);
+        bwd_data_batch<KH, KW, 1>(one, gq, win, wr, shift, has_halo, active, skip, W);
+    }
+    if constexpr (TR > 0)
+        bwd_data_batch<KH, KW, TR>(tail, gq, win, wr, shift, has_halo, active, skip, W);
+}
+
+// ------------------------------------------------------------------------------------------
 // fixed-order float64 reduction of per-block partials: one wave per output entry.
 // partial is [nparts][nent]; out_w gets entries [0, nw), out_b gets [nw, nent).
 __global__ __launch_bounds__(64) void reduce_partials_kernel(const double *__restrict__ partial,
@@ -782,13 +1011,16 @@ bool flat_plan(K kernel, int N, int OH, int OW, int W, int kH, const void *x, co
     p->waves = (OW + cols_per_wave - 1) / cols_per_wave;
     if (p->waves > 16) return false;
     int ring = 1024;
-    while (ring < RB * OW + 8) ring *= 2;
+    const int ring_rows = FRB > kH - 1 ? FRB : kH - 1;     // the largest batch: FRB rows or the tail
+    while (ring < ring_rows * OW + 8) ring *= 2;
     if (ring > 16384) return false;                                  // 64 KB of LDS
     p->ring = ring;
     (void)kernel;
     const long long total_rows = (long long)N * OH;
-    int rows = 3 * RB - (kH - 1);
-    if (rows < RB) rows = RB;
+    // forward: WM_FWD_BATCHES full load batches per range; the KH-1 rows the range shares with
+    // its successor are loaded up front on top of them (kept in registers)
+    int rows = WM_KNOB(WM_FWD_BATCHES) * FRB;
+    if (target_segs > 0) rows = 3 * RB - (kH - 1);
     long long segs = (total_rows + rows - 1) / rows;
     // target_segs > 0 (backward, reads only: long ranges cost nothing and halve the halo): one
     // range per workgroup, as even as possible
@@ -910,9 +1142,11 @@ extern "C" int wm_conv2d_fwd_f32(const float *x, const float *w, const float *b,
     if (KH_ * KW_ <= 9 &&                                                                       \
         flat_plan(conv_fwd_c1f_kernel<KH_, KW_>, N, OH, OW, W, kH, x, y, WaveCols<KW_>::CW,     \
                   &fp)) {                                                                       \
+        size_t lds_ = (size_t)fp.ring * sizeof(float);                                         \
+        if (lds_ < (size_t)WM_KNOB(WM_FWD_LDS_MIN)) lds_ = (size_t)WM_KNOB(WM_FWD_LDS_MIN);                     \
         hipLaunchKernelGGL((conv_fwd_c1f_kernel<KH_, KW_>), dim3(fp.segs), dim3(fp.waves * 64), \
-                           (size_t)fp.ring * sizeof(float), st, x, w, b, y, H, W, OH, OW,       \
-                           fp.rows_base, fp.rows_rem, relu, fp.ring - 1);                       \
+                           lds_, st, x, w, b, y, H, W, OH, OW,                                  \
+                           fp.rows_base, fp.rows_rem, relu, fp.ring - 1, WM_KNOB(WM_FWD_XCD_RUN)); \
         WM_LAUNCH_CHECK("conv_fwd_c1f_kernel");                                                 \
         return WM_OK;                                                                           \
     }
@@ -949,6 +1183,27 @@ extern "C" int wm_conv2d_bwd_data_f32(const float *gy, const float *w, float *gx
     if (mfma_shape(N, Cin, H, W, Cout, kH, kW))
         return wm_conv3d_bwd_data_f32(gy, w, gx, N, Cin, 1, H, W, Cout, 1, kH, kW, stream);
     const int OH = H - kH + 1, OW = W - kW + 1;
+    // single-channel stencil with 16-byte aligned output rows: the flat kernel
+    if (stencil_shape(Cin, Cout, kH, kW, OW, (long long)N * H) && kH * kW <= 9 && kW <= 3 &&
+        W % 4 == 0 && OW >= 4 && W <= 4096 && ((uintptr_t)gx & 15) == 0) {
+        const long long total_rows = (long long)N * H;
+        const int rows = WM_KNOB(WM_FWD_BATCHES) * FRB;
+        const long long segs = (total_rows + rows - 1) / rows;
+        if (segs <= 0x7fffffffLL) {
+            const unsigned rows_base = (unsigned)(total_rows / segs);
+            const unsigned rows_rem = (unsigned)(total_rows % segs);
+            const unsigned last_row = (unsigned)((long long)N * OH - 1);
+            const int threads = (W / 4 + 63) / 64 * 64;
+#define BWDD(KH_, KW_)                                                                          \
+    hipLaunchKernelGGL((conv_bwd_data_c1f_kernel<KH_, KW_>), dim3((unsigned)segs),              \
+                       dim3(threads), 0, st, gy, w, gx, H, W, OH, OW, last_row, rows_base,      \
+                       rows_rem, WM_KNOB(WM_FWD_XCD_RUN));
+            WM_STENCIL_DISPATCH(BWDD)
+#undef BWDD
+            WM_LAUNCH_CHECK("conv_bwd_data_c1f_kernel");
+            return WM_OK;
+        }
+    }
     const long long total = (long long)N * Cin * H * W;
     hipLaunchKernelGGL(conv_bwd_data_generic_kernel, dim3(generic_grid(total)), dim3(BLOCK), 0, st,
                        gy, w, gx, N, Cin, H, W, Cout, kH, kW, OH, OW);

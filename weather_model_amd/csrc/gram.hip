@@ -880,6 +880,7 @@ extern "C" int wm_linear_predict_f32(const float *X, const double *beta, float *
     WM_REQUIRE(X && beta && Yhat, WM_ERR_INVALID, "wm_linear_predict_f32: null pointer");
     WM_REQUIRE(F > 0 && P > 0 && n >= 0, WM_ERR_INVALID, "wm_linear_predict_f32: bad sizes");
     if (n == 0) return WM_OK;
+    WM_REQUIRE(wm_num_cus() > 0, WM_ERR_NO_DEVICE, "wm_linear_predict_f32: no HIP device");
     long long g = ((long long)n * P + BLOCK - 1) / BLOCK;
     const long long cap = (long long)wm_num_cus() * 16;
     if (g > cap) g = cap;

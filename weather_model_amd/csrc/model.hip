@@ -667,21 +667,26 @@ __global__ __launch_bounds__(256) void model_grad_finalize_kernel(const double *
     }
 }
 
-// torch.optim.Adam defaults semantics (newConvolution.py:225): no weight decay, no amsgrad
+// torch.optim.Adam defaults semantics (newConvolution.py:225): no weight decay, no amsgrad.  The
+// operation order is the single-tensor path of torch.optim.Adam: lerp for the first moment,
+// mul + addcmul for the second, denom = sqrt(v) / sqrt(bc2) + eps, p += (-lr / bc1) * (m / denom);
+// every scalar is computed in double on the host and rounded to float once, as torch does.
 __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ gr,
                                                    float *__restrict__ m, float *__restrict__ v,
-                                                   long long count, float lr, float b1, float b2,
-                                                   float eps, float bc1, float bc2_sqrt, float gscale)
+                                                   long long count, float one_minus_b1, float b2,
+                                                   float one_minus_b2, float eps, float step_size,
+                                                   float bc2_sqrt, float gscale)
 {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= count) return;
     const float gv = gr[idx] * gscale;
-    const float mn = b1 * m[idx] + (1.0f - b1) * gv;
-    const float vn = b2 * v[idx] + (1.0f - b2) * gv * gv;
+    const float mo = m[idx];
+    const float mn = mo + one_minus_b1 * (gv - mo);
+    const float vn = b2 * v[idx] + (one_minus_b2 * gv) * gv;
     m[idx] = mn;
     v[idx] = vn;
     const float denom = sqrtf(vn) / bc2_sqrt + eps;
-    p[idx] = p[idx] - (lr / bc1) * (mn / denom);
+    p[idx] = p[idx] - step_size * (mn / denom);
 }
 
 int model_grid(long long B)
@@ -800,17 +805,20 @@ extern "C" int wm_model_train_f32(const float *params, const float *x, const flo
 }
 
 extern "C" int wm_adam_step_f32(float *params, const float *grads, float *m, float *v,
-                                int64_t count, int step, float lr, float beta1, float beta2,
-                                float eps, float grad_scale, void *stream)
+                                int64_t count, int step, double lr, double beta1, double beta2,
+                                double eps, float grad_scale, void *stream)
 {
     WM_REQUIRE(params && grads && m && v, WM_ERR_INVALID, "wm_adam_step_f32: null pointer");
     WM_REQUIRE(count >= 0 && step >= 1, WM_ERR_INVALID, "wm_adam_step_f32: bad count/step");
     if (count == 0) return WM_OK;
-    const float bc1 = 1.0f - powf(beta1, (float)step);
-    const float bc2 = 1.0f - powf(beta2, (float)step);
+    // bias corrections in double, like torch (1 - beta ** step in Python floats): in float32
+    // 1 - 0.999f is already off by 1.3e-5 relative, a systematic error in every early update
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, params, grads, m, v, (long long)count, lr, beta1, beta2,
-                       eps, bc1, sqrtf(bc2), grad_scale);
+                       (hipStream_t)stream, params, grads, m, v, (long long)count,
+                       (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
+                       (float)(lr / bc1), (float)sqrt(bc2), grad_scale);
     WM_LAUNCH_CHECK("adam_kernel");
     return WM_OK;
 }

@@ -312,19 +312,43 @@ class GramPlan:
         sb = L.wm_normal_solve_workspace_bytes(self.F, self.P)
         self.solve_ws = torch.empty((max(sb, 8),), device=self.device, dtype=torch.uint8)
 
+    def _rows(self, t, name, cols):
+        """A (n, cols) float32 contiguous tensor on this plan's device with n <= the planned rows."""
+        if not isinstance(t, torch.Tensor) or not t.is_cuda or t.device != self.acc.device:
+            raise RuntimeError(f"{name} must be a tensor on {self.acc.device} (no CPU fallback)")
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise TypeError(f"{name} must be contiguous float32, got {t.dtype}, "
+                            f"contiguous={t.is_contiguous()}")
+        if t.dim() == 1 and cols == 1:
+            t = t[:, None]
+        if t.dim() != 2 or t.shape[1] != cols:
+            raise ValueError(f"{name} must be (n, {cols}), got {tuple(t.shape)}")
+        if t.shape[0] > self.n:
+            raise ValueError(f"{name} has {t.shape[0]} rows, the plan was made for {self.n}")
+        return t
+
     def accumulate(self, X, Y):
+        """acc += Gram of the rows of X, Y (any row count up to the planned n)."""
+        X = self._rows(X, "X", self.F)
+        Y = self._rows(Y, "Y", self.P)
+        if Y.shape[0] != X.shape[0]:
+            raise ValueError(f"X has {X.shape[0]} rows, Y has {Y.shape[0]}")
+        if X.shape[0] == 0:
+            return
         L = _lib.lib()
-        _lib.check(L.wm_gram_f32(X.data_ptr(), Y.data_ptr(), self.n, self.F, self.P,
-                                 self.acc.data_ptr(), self.ws.data_ptr(), self.ws.numel(),
-                                 _stream()))
+        with torch.cuda.device(self.acc.device):
+            _lib.check(L.wm_gram_f32(X.data_ptr(), Y.data_ptr(), X.shape[0], self.F, self.P,
+                                     self.acc.data_ptr(), self.ws.data_ptr(), self.ws.numel(),
+                                     _stream()))
 
     def solve(self, fit_intercept=True, ridge=0.0):
         L = _lib.lib()
-        _lib.check(L.wm_normal_solve_f64(self.acc.data_ptr(), self.F, self.P,
-                                         int(bool(fit_intercept)), float(ridge),
-                                         self.beta.data_ptr(), self.status.data_ptr(),
-                                         self.solve_ws.data_ptr(), self.solve_ws.numel(),
-                                         _stream()))
+        with torch.cuda.device(self.acc.device):
+            _lib.check(L.wm_normal_solve_f64(self.acc.data_ptr(), self.F, self.P,
+                                             int(bool(fit_intercept)), float(ridge),
+                                             self.beta.data_ptr(), self.status.data_ptr(),
+                                             self.solve_ws.data_ptr(), self.solve_ws.numel(),
+                                             _stream()))
         return self.beta
 
 
@@ -394,9 +418,11 @@ def field_stats(x, out=None):
 def affine_scale(x, offset, divisor, out=None):
     """(x - offset) / divisor in float32 (normalize / standardize of the reference)."""
     x = _req(x, "field")
+    if out is not None and (not isinstance(out, torch.Tensor) or not out.is_contiguous()):
+        raise ValueError("out must be a contiguous tensor (a copy would swallow the result)")
     y = torch.empty_like(x) if out is None else _req(out, "out")
-    if y.shape != x.shape:
-        raise ValueError("out has a different shape")
+    if y.shape != x.shape or y.device != x.device:
+        raise ValueError("out has a different shape or device")
     with torch.cuda.device(x.device):
         _lib.check(_lib.lib().wm_affine_scale_f32(x.data_ptr(), y.data_ptr(), x.numel(),
                                                   float(offset), float(divisor), _stream()))
@@ -513,10 +539,21 @@ def model_train(flat_params, x, y=None, dout=None, batch_global=None, ws=None):
 
 
 def adam_step(params, grads, m, v, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    """In-place torch.optim.Adam step on flat float32 buffers (newConvolution.py:185,225)."""
+    for name, t in (("params", params), ("grads", grads), ("m", m), ("v", v)):
+        if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.float32 or \
+                not t.is_contiguous():
+            raise TypeError(f"adam_step: {name} must be a contiguous float32 CUDA tensor")
+        if t.numel() != params.numel() or t.device != params.device:
+            raise ValueError(f"adam_step: {name} has {t.numel()} elements on {t.device}, params has "
+                             f"{params.numel()} on {params.device}")
+    if int(step) < 1:
+        raise ValueError("adam_step: step counts from 1")
     with torch.cuda.device(params.device):
         _lib.check(_lib.lib().wm_adam_step_f32(params.data_ptr(), grads.data_ptr(), m.data_ptr(),
-                                               v.data_ptr(), params.numel(), int(step), lr, beta1,
-                                               beta2, eps, grad_scale, _stream()))
+                                               v.data_ptr(), params.numel(), int(step), float(lr),
+                                               float(beta1), float(beta2), float(eps),
+                                               float(grad_scale), _stream()))
 
 
 class ModelFunction(torch.autograd.Function):
