@@ -4,7 +4,7 @@
 # the first pass that fails.  Summarise with tools/pmc_summarise.py.
 set -u
 cd /tmp && export TMPDIR=/tmp
-OUT=/root/repo/gpurun_out/pmc_bench
+OUT=/root/repo/gpurun_out/${PMC_TAG:-pmc_bench}
 mkdir -p $OUT
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE"; do

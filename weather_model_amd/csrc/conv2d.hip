@@ -54,10 +54,13 @@ constexpr int RB = WM_STENCIL_RB;
 #endif
 constexpr int FRB = WM_FWD_RB;      // rows per load batch of the flat forward kernel
 #ifndef WM_FWD_BATCHES
-#define WM_FWD_BATCHES 3
+#define WM_FWD_BATCHES 2
 #endif
 #ifndef WM_FWD_XCD_RUN
-#define WM_FWD_XCD_RUN 8
+#define WM_FWD_XCD_RUN 16
+#endif
+#ifndef WM_BWD_OCC_CAP
+#define WM_BWD_OCC_CAP 6
 #endif
 #ifndef WM_FWD_LDS_MIN
 #define WM_FWD_LDS_MIN 0
@@ -294,7 +297,9 @@ __device__ __forceinline__ void fwd_batch_f(const f32x4 (&rows)[NB], float *ring
             }
         fo.flushed = lim;
     }
-    __syncthreads();
+    // No second barrier: the ring holds TWO batches.  A wave that runs ahead writes batch k+1 into
+    // the half that flush k does not read, and cannot reach batch k+2 before the barrier of batch
+    // k+1, which every wave passes only after it has finished flush k.
 }
 
 // one workgroup (wq_per_row waves) = one contiguous range of output rows
@@ -354,9 +359,6 @@ __global__ __launch_bounds__(1024) void conv_fwd_c1f_kernel(
 #pragma unroll
         for (int e = 0; e < EXT; ++e) win[kh][e] = 0.0f;
 
-    // the loads of batch k+1 are in flight while batch k is consumed and flushed (the barriers of
-    // the flush would otherwise leave the memory pipe idle); the last batch re-reads its own rows
-    // instead of branching around the loads
     // The last KH-1 input rows of this range are the first rows of the next range, which its
     // workgroup (same XCD, dispatched a moment later) loads at the START of its life.  They are
     // loaded here first as well and kept in registers until the end: both reads then fall within
@@ -370,16 +372,16 @@ __global__ __launch_bounds__(1024) void conv_fwd_c1f_kernel(
     }
     const int main_steps = steps - TR;
     const int nfull = main_steps / FRB;
-    f32x4 cur[FRB], nxt[FRB];
-    if (nfull > 0) load_rows_f<KH, KW, FRB>(cur, xq, W);
+    // One batch in flight per wave, no software prefetch: the other workgroups of the CU cover the
+    // latency, and FEWER bytes in flight measured faster (a plain grid-stride copy of the same
+    // buffers runs 88.6 us with 3 MB in flight and 100-109 us with 8 MB; this kernel 96 -> 90 us
+    // on a cool chip when the double-buffered batch went away).
     for (int bi = 0; bi < nfull; ++bi) {
-        const float *__restrict__ xn = xq + (bi + 1 < nfull ? (size_t)FRB * W : (size_t)0);
-        load_rows_f<KH, KW, FRB>(nxt, xn, W);
+        f32x4 cur[FRB];
+        load_rows_f<KH, KW, FRB>(cur, xq, W);
         xq += (size_t)FRB * W;
         __builtin_amdgcn_sched_barrier(0);
         fwd_batch_f<KH, KW, FRB>(cur, ring, fo, win, wr, bias, relu, j0, nst, h, hmin, H, OW);
-#pragma unroll
-        for (int u = 0; u < FRB; ++u) cur[u] = nxt[u];
     }
     for (int s = nfull * FRB; s < main_steps; ++s) {
         f32x4 one[1];
@@ -607,10 +609,11 @@ __global__ __launch_bounds__(1024) void conv_bwd_wb_c1f_kernel(
         if (lane == 0) red[wq][NV - 1] = s;
     }
     __syncthreads();
+    // entry-major partials [NV][gridDim.x]: the finalize kernel then reads them coalesced
     if (threadIdx.x < NV) {
         double s = 0.0;
         for (int v = 0; v < nwaves; ++v) s += (double)red[v][threadIdx.x];
-        partial[(size_t)blockIdx.x * NV + threadIdx.x] = s;
+        partial[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = s;
     }
 }
 
@@ -766,19 +769,11 @@ __global__ __launch_bounds__(1024) void conv_bwd_data_c1f_kernel(
     }
     const int main_steps = steps - TR;
     const int nfull = main_steps / FRB;
-    GyRow cur[FRB], nxt[FRB];
-    if (nfull > 0) load_gy_rows<FRB>(cur, gy, OW, OH, H, last_row, jg, jh, p, gr);
     for (int bi = 0; bi < nfull; ++bi) {
-        // the batch after the last full one is loaded too (always in bounds) and either feeds the
-        // single-row steps below or is dropped
-        int pn = p;
-        unsigned grn = gr;
-        load_gy_rows<FRB>(nxt, gy, OW, OH, H, last_row, jg, jh, pn, grn);
-        if (bi + 1 < nfull) { p = pn; gr = grn; }
+        GyRow cur[FRB];
+        load_gy_rows<FRB>(cur, gy, OW, OH, H, last_row, jg, jh, p, gr);
         __builtin_amdgcn_sched_barrier(0);
         bwd_data_batch<KH, KW, FRB>(cur, gq, win, wr, shift, has_halo, active, skip, W);
-#pragma unroll
-        for (int u = 0; u < FRB; ++u) cur[u] = nxt[u];
     }
     for (int s = nfull * FRB; s < main_steps; ++s) {
         GyRow one[1];
@@ -804,6 +799,28 @@ __global__ __launch_bounds__(64) void reduce_partials_kernel(const double *__res
     if (threadIdx.x == 0) {
         if (e < nw) out_w[e] = (float)s;
         else if (out_b) out_b[e - nw] = (float)s;
+    }
+}
+
+// The same for entry-major partials [nent][nparts] (the flat stencil kernel): one 256-thread
+// workgroup per entry, coalesced 8-byte loads, fixed order (thread t adds partials t, t+256, ...;
+// butterfly across the wave; the four wave sums in wave order).
+__global__ __launch_bounds__(256) void reduce_partials_wide_kernel(
+    const double *__restrict__ partial, int nparts, int nw, float *__restrict__ out_w,
+    float *__restrict__ out_b)
+{
+    __shared__ double wsum[4];
+    const int e = blockIdx.x;
+    const double *__restrict__ src = partial + (size_t)e * nparts;
+    double s = 0.0;
+    for (int p = threadIdx.x; p < nparts; p += 256) s += src[p];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double t = ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
+        if (e < nw) out_w[e] = (float)t;
+        else if (out_b) out_b[e - nw] = (float)t;
     }
 }
 
@@ -1012,7 +1029,7 @@ bool flat_plan(K kernel, int N, int OH, int OW, int W, int kH, const void *x, co
     if (p->waves > 16) return false;
     int ring = 1024;
     const int ring_rows = FRB > kH - 1 ? FRB : kH - 1;     // the largest batch: FRB rows or the tail
-    while (ring < ring_rows * OW + 8) ring *= 2;
+    while (ring < 2 * ring_rows * OW + 8) ring *= 2;      // two batches: see fwd_batch_f
     if (ring > 16384) return false;                                  // 64 KB of LDS
     p->ring = ring;
     (void)kernel;
@@ -1248,7 +1265,6 @@ extern "C" int wm_conv2d_bwd_wb_f32(const float *x, const float *gy, float *gw, 
     const int nw = Cout * Cin * kH * kW, nent = nw + Cout;
     double *partial = (double *)workspace;
     int nparts = 0;
-    bool flat_done = false;
     if (stencil_shape(Cin, Cout, kH, kW, OW, (long long)N * H)) {
 #define BWDF(KH_, KW_)                                                                          \
     FlatPlan fp;                                                                                \
@@ -1258,7 +1274,7 @@ extern "C" int wm_conv2d_bwd_wb_f32(const float *x, const float *gy, float *gw, 
         if (int rc = cached_occupancy(conv_bwd_wb_c1f_kernel<KH_, KW_>, waves_ * 64, &occ))     \
             return rc;                                                                          \
         if (occ * waves_ > 30) occ = 30 / waves_;                                               \
-        if (occ > 6) occ = 6;                                                                   \
+        if (occ > WM_KNOB(WM_BWD_OCC_CAP)) occ = WM_KNOB(WM_BWD_OCC_CAP);                       \
         if (occ < 1) occ = 1;                                                                   \
     }                                                                                           \
     if (occ > 0 &&                                                                              \
@@ -1268,14 +1284,15 @@ extern "C" int wm_conv2d_bwd_wb_f32(const float *x, const float *gy, float *gw, 
                            dim3(fp.waves * 64), 0, st, x, gy, partial, H, W, OH, OW,            \
                            fp.rows_base, fp.rows_rem, (unsigned)fp.segs);                       \
         WM_LAUNCH_CHECK("conv_bwd_wb_c1f_kernel");                                              \
-        nparts = fp.segs;                                                                       \
-        flat_done = true;                                                                       \
+        hipLaunchKernelGGL(reduce_partials_wide_kernel, dim3(nent), dim3(256), 0, st, partial,  \
+                           fp.segs, nw, gw, gb);                                                \
+        WM_LAUNCH_CHECK("reduce_partials_wide_kernel");                                         \
+        return WM_OK;                                                                           \
     }
         WM_STENCIL_DISPATCH(BWDF)
 #undef BWDF
     }
-    if (flat_done) {
-    } else if (stencil_shape(Cin, Cout, kH, kW, OW, (long long)N * H)) {
+    if (stencil_shape(Cin, Cout, kH, kW, OW, (long long)N * H)) {
 #define BWD(KH_, KW_)                                                                         \
     StencilPlan p;                                                                            \
     if (int rc = stencil_plan(conv_bwd_wb_c1_kernel<KH_, KW_>, N, OH, OW, &p)) return rc;     \
