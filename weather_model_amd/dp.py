@@ -45,6 +45,21 @@ def allreduce_sum_(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
+def broadcast_(t: torch.Tensor, src: int = 0) -> torch.Tensor:
+    """In-place broadcast of one contiguous buffer from rank `src` (no-op for a single process):
+    replicas must start from the SAME weights, whatever each process's RNG produced."""
+    if world() > 1:
+        if not t.is_contiguous():
+            raise ValueError("broadcast needs one contiguous buffer")
+        if t.is_cuda and dist.get_backend() == "gloo":
+            host = t.cpu()
+            dist.broadcast(host, src=src)
+            t.copy_(host)
+        else:
+            dist.broadcast(t, src=src)
+    return t
+
+
 def reduce_gram_(acc: torch.Tensor) -> torch.Tensor:
     """Partial Gram matrices of the row shards -> the Gram of all rows, on every rank."""
     if acc.dtype != torch.float64:

@@ -249,9 +249,15 @@ class DeviceTrainer:
         self.model = model
         self.lr, self.betas, self.eps = lr, betas, eps
         self.flat = model.flat_parameters().detach().clone().contiguous()
+        # every replica starts from rank 0's weights: each process initialised its module from
+        # its own RNG, and the same summed gradient applied to different weights is the gradient
+        # of no model at all
+        dp.broadcast_(self.flat)
         self.m = torch.zeros_like(self.flat)
         self.v = torch.zeros_like(self.flat)
         self.step = 0
+        if dp.world() > 1:
+            self.sync_to_model()
 
     def epoch(self, dataset, batch_size, shuffle=True, seed=0, max_batches=None):
         """One pass over ``dataset`` (a CustomDataset); returns the mean batch loss."""
@@ -265,16 +271,21 @@ class DeviceTrainer:
         for start in range(0, n, batch_size):
             idx = order[start:start + batch_size]
             mine = idx[rank::world]                      # this rank's share of the global batch
-            if mine.numel() == 0:
-                continue
-            x, y = dataset.batch(mine, device=dev)
-            _, loss, grads = ops.model_train(self.flat, x, y, batch_global=int(idx.numel()))
+            # A rank whose share is empty (last batch smaller than the world) still takes part in
+            # the collective, the Adam step and the batch count -- with a zero gradient and a zero
+            # loss share.  Skipping it would pair this rank's NEXT collective with the others'
+            # current one.
+            if mine.numel() > 0:
+                x, y = dataset.batch(mine, device=dev)
+                _, loss, grads = ops.model_train(self.flat, x, y, batch_global=int(idx.numel()))
+                total += loss
+            else:
+                grads = torch.zeros_like(self.flat)
             self._dp.reduce_grads_(grads)
             self.step += 1
             ops.adam_step(self.flat, grads, self.m, self.v, self.step, self.lr, self.betas[0],
                           self.betas[1], self.eps)
-            total += loss
-            batches += 1
+            batches += 1                                 # counts GLOBAL batches: equal on all ranks
             if max_batches is not None and batches >= max_batches:
                 break
         if world > 1:
