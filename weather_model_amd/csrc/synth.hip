@@ -54,6 +54,43 @@ __global__ __launch_bounds__(BLOCK) void synth_regression_kernel(
     }
 }
 
+// Fast path (F a multiple of 4 with F/4 a power of two <= 64, P = 1): G = F/4 lanes share a row,
+// each hashes its four features and stores them as ONE 16-byte piece, so a wave writes a contiguous
+// KiB of X per instruction (the kernel above writes 4 bytes per lane at a stride of one row: 0.33
+// TB/s on the 1.25e9 x 64 rows of config 5, where generation then took 16x the Gram pass).  The
+// row's dot product with beta is summed across its G lanes by a butterfly; X is bit for bit what
+// the per-row kernel and weather_model_amd/synth.py produce, Y agrees to float32 rounding.
+template <int G>
+__global__ __launch_bounds__(BLOCK) void synth_regression_rows_kernel(
+    float *__restrict__ X, float *__restrict__ Y, long long n, int F, uint64_t seed,
+    uint64_t row_offset, const float *__restrict__ beta, float intercept, float noise, int dist)
+{
+    constexpr int RPW = 64 / G;                       // rows per wave and iteration
+    const int lane = threadIdx.x & 63;
+    const int g = lane % G, rl = lane / G;
+    const long long wave = (long long)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    const long long nwaves = (long long)gridDim.x * (BLOCK / 64);
+    const f32x4 b = *reinterpret_cast<const f32x4 *>(beta + 4 * g);
+    for (long long r0 = wave * RPW; r0 < n; r0 += nwaves * RPW) {
+        const long long r = min(r0 + rl, n - 1);      // clamped: every lane takes part in the sum
+        const uint64_t gr = row_offset + (uint64_t)r;
+        const uint64_t e0 = gr * (uint64_t)F + (uint64_t)(4 * g);
+        f32x4 xv;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint64_t z = hash64(seed, e0 + k);
+            xv[k] = dist ? gauss(z) : u01(z);
+        }
+        float s = fmaf(xv[3], b[3], fmaf(xv[2], b[2], fmaf(xv[1], b[1], xv[0] * b[0])));
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (r0 + rl < n) {
+            __builtin_nontemporal_store(xv, reinterpret_cast<f32x4 *>(X + r * F + 4 * g));
+            if (g == 0) Y[r] = (s + intercept) + noise * gauss(hash64(seed + 2000, gr));
+        }
+    }
+}
+
 int grid_for(long long count)
 {
     long long g = (count + BLOCK - 1) / BLOCK;
@@ -85,6 +122,28 @@ extern "C" int wm_synth_regression_f32(float *X, float *Y, int64_t n, int F, int
                "wm_synth_regression_f32: bad arguments");
     if (n == 0) return WM_OK;
     WM_REQUIRE(wm_num_cus() > 0, WM_ERR_NO_DEVICE, "wm_synth_regression_f32: no HIP device");
+    const int G = F / 4;
+    if (P == 1 && F % 4 == 0 && G <= 64 && (G & (G - 1)) == 0 &&
+        (((uintptr_t)X | (uintptr_t)beta) & 15) == 0) {
+        const long long waves = (n + 64 / G - 1) / (64 / G);
+        const int grid = grid_for(waves * 64);
+#define WM_SYNTH_ROWS(G_)                                                                      \
+    hipLaunchKernelGGL(synth_regression_rows_kernel<G_>, dim3(grid), dim3(BLOCK), 0,           \
+                       (hipStream_t)stream, X, Y, (long long)n, F, seed, row_offset, beta,     \
+                       intercept, noise, dist)
+        switch (G) {
+        case 1: WM_SYNTH_ROWS(1); break;
+        case 2: WM_SYNTH_ROWS(2); break;
+        case 4: WM_SYNTH_ROWS(4); break;
+        case 8: WM_SYNTH_ROWS(8); break;
+        case 16: WM_SYNTH_ROWS(16); break;
+        case 32: WM_SYNTH_ROWS(32); break;
+        default: WM_SYNTH_ROWS(64); break;
+        }
+#undef WM_SYNTH_ROWS
+        WM_LAUNCH_CHECK("synth_regression_rows_kernel");
+        return WM_OK;
+    }
     hipLaunchKernelGGL(synth_regression_kernel, dim3(grid_for(n)), dim3(BLOCK), 0,
                        (hipStream_t)stream, X, Y, (long long)n, F, P, seed, row_offset, beta,
                        intercept, noise, dist);
