@@ -209,6 +209,28 @@ int wm_gather_triplets_f32(const float *vol, const int64_t *idx, int64_t idx0, f
                            int St, int Sz, int Sy, int Sx, int time_offset, int d_mid, int d_end,
                            void *stream);
 
+/* Row construction of the regression generators from a RESIDENT volume, replacing the np.append
+ * growth of WeatherDataGenerator.__getitem__ / gather_batches (multipleRegression.py:217-257), the
+ * per-sample NetCDF reads of WeatherGenerator (singleRegression.py:251-299) and the random cubes of
+ * DataGenerator (convolution.py:118-147).  vol is (files, nvars, Z, Y, X) float32.  Row r takes the
+ * (cz,cy,cx) cube of every variable at origin (z0,y0,x0) from files f, f + d_end, f + d_mid:
+ *   x1out[r*xstride + .] = cube(vol[f]),  x2out[r*xstride + .] = cube(vol[f + d_end]),
+ *   yout[r*p + .] = cube(vol[f + d_mid]),   p = nvars*cz*cy*cx, flattened (var, dz, dy, dx).
+ * For the regression rows [x1 | x2] pass x2out = x1out + p and xstride = 2p.
+ * origins != NULL: int32 (rows, 4) = (f, z0, y0, x0) per row (device memory).
+ * origins == NULL: the reference's region walk (multipleRegression.py:259-270) in closed form,
+ * `batch` rows per generator batch, starting from the generator state (index0; r0, r1, r2 = the
+ * raw region_index) with period `length` and region moduli (dim_z, dim_y, dim_x) = data_dim[1:]:
+ * batch b has file (index0+b) % length * batch + j and origin
+ * (R0_b % dim_z, R1_b % dim_y, R2_b % dim_x), R0_b = (index0+b)/length, R1_b = R0_{b-1}/dim_z,
+ * R2_b = R1_{b-1}/dim_y for b >= 1. */
+int wm_gather_cubes_f32(const float *vol, int files, int nvars, int Z, int Y, int X,
+                        int cz, int cy, int cx, int d_mid, int d_end,
+                        const int32_t *origins, int64_t rows, int batch, int64_t length,
+                        int64_t index0, int64_t r0, int64_t r1, int64_t r2,
+                        int dim_z, int dim_y, int dim_x,
+                        float *x1out, float *x2out, int64_t xstride, float *yout, void *stream);
+
 /* ------------------------------------------------------------------ synthetic data ------ */
 
 /* Counter-based generator: element i of `out` depends only on (seed, offset + i).  Same hash as

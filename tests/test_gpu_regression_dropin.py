@@ -58,25 +58,37 @@ def test_multiple_regression_fit_matches_lstsq():
     hist, mod = mr.fit_model_with_generator(model, n_files, input_shape, data_dim, it,
                                             all_data, stats)
     assert mod is model
-    assert hist.epoch == [0]
+    # epochs as in Keras: every epoch consumes the NEXT steps_per_epoch batches of the walking
+    # generator; EarlyStopping(loss, patience=2) ends the run (multipleRegression.py:339-350)
+    E = len(hist.epoch)
+    assert hist.epoch == list(range(E)) and 3 <= E <= mr.EPOCHS[it]
     assert set(hist.history) == {"loss", "mae", "msle", "val_loss", "val_mae", "val_msle"}
+    assert all(len(v) == E for v in hist.history.values())
+    assert hist.params["solver"].startswith("closed-form") and "unpinned" in hist.params["parity"]
+    assert hist.params["metrics_from"] == "rows"
 
-    # the same rows, gathered independently
+    # the same rows, gathered independently ON THE HOST (fit took them from the device walk)
     bs = mr.BATCH_SIZE[it]
     steps = int((((n_files * 0.8) // bs) - 1) * 8)
     length = int(((n_files * 0.8) // bs) - (mr.TIME_SPAN // bs) - 1)
     gen = mr.WeatherDataGenerator(n_files, input_shape, length, data_dim, it, all_data, start,
                                   stats)
-    x1, x2, y = gen.rows(steps)
+    x1, x2, y = gen.rows(steps * E)
     X = np.concatenate([x1.reshape(len(x1), -1), x2.reshape(len(x2), -1)], axis=1)
-    assert model.rows_seen == len(X) == steps * bs
+    assert model.rows_seen == len(X) == steps * bs * E
     beta = _lstsq(X, y)
     K, c = model.coefficients
     got = np.concatenate([K, c[None]], axis=0)
     assert np.abs(got - beta).max() / np.abs(beta).max() < 1e-4
-    resid = np.concatenate([X, np.ones((len(X), 1))], 1) @ beta - y
-    assert hist.history["loss"][0] == pytest.approx(float((resid ** 2).mean()), rel=1e-3)
-    assert hist.history["mae"][0] == pytest.approx(float(np.abs(resid).mean()), rel=1e-3)
+    # the last epoch's loss / mae: the final map over the last epoch's rows
+    last = slice((E - 1) * steps * bs, None)
+    resid = np.concatenate([X[last], np.ones((steps * bs, 1))], 1) @ beta - y[last]
+    assert hist.history["loss"][-1] == pytest.approx(float((resid ** 2).mean()), rel=1e-3)
+    assert hist.history["mae"][-1] == pytest.approx(float(np.abs(resid).mean()), rel=1e-3)
+    # the first epoch's loss: the fit over the first epoch's rows alone
+    b0 = _lstsq(X[:steps * bs], y[:steps * bs])
+    r0 = np.concatenate([X[:steps * bs], np.ones((steps * bs, 1))], 1) @ b0 - y[:steps * bs]
+    assert hist.history["loss"][0] == pytest.approx(float((r0 ** 2).mean()), rel=1e-3)
 
     pred = model.predict([x1[:5], x2[:5]])
     assert pred.shape == (5, 1) and pred.dtype == np.float32
@@ -163,3 +175,121 @@ def test_fit_streams_many_chunks():
     beta = _lstsq(np.concatenate([x1, x2], 1), y)
     assert np.abs(np.concatenate([Kb, cb[None]]) - beta).max() / np.abs(beta).max() < 1e-4
     assert torch.cuda.is_available()
+
+
+def test_device_rows_bit_exact_vs_host_generator():
+    """Row a9: wm_gather_cubes_f32's closed-form region walk against the drop-in's host generator
+    (the literal update rule of multipleRegression.py:259-270), bit for bit, over enough batches
+    for all three region coordinates to move; then with 2^3 cubes of three variables."""
+    n_files = 120
+    mr = _mr(n_files, (1, 12, 14, 14))
+    stats = [mr.DATA_VARS_MIN, mr.DATA_VARS_MAX, mr.DATA_VARS_MEAN, mr.DATA_VARS_STD]
+    all_data = mr.load_data(n_files, 0, stats)
+    start = int(n_files * mr.VALIDATION_SPLIT)
+    for it, cube, tested, bs in ((0, 1, ("T",), 16), (1, 2, ("T", "QVAPOR", "W"), 4)):
+        mr.CUBE_SIZE = tuple(cube if k == it else 1 for k in range(mr.TOTAL_ITERATIONS))
+        mr.BATCH_SIZE = tuple(bs if k == it else 16 for k in range(mr.TOTAL_ITERATIONS))
+        mr.VARIABLE_TEST[it] = {d: d in tested for d in mr.DATA_VARS}
+        input_shape = mr.calculate_input_shape(it)
+        data_dim = mr.calculate_data_shape(it)                       # (1, 2, 2, 2)
+        length = int(((n_files * 0.8) // bs) - (mr.TIME_SPAN // bs) - 1)
+        mk = lambda: mr.WeatherDataGenerator(n_files, input_shape, length, data_dim, it,    # noqa: E731
+                                             all_data, start, stats)
+        host, dev = mk(), mk()
+        assert dev.device_ready()
+        count = 9 * length + 3                   # region_index reaches (9, 4, 2): all three move
+        x1, x2, y = host.rows(count)
+        Xh = np.concatenate([x1.reshape(len(x1), -1), x2.reshape(len(x2), -1)], axis=1)
+        # in three uneven pieces: the walk must resume from the saved state
+        parts = [dev.device_rows(k) for k in (5, length + 1, count - length - 6)]
+        Xd = torch.cat([p[0] for p in parts]).cpu().numpy()
+        Yd = torch.cat([p[1] for p in parts]).cpu().numpy()
+        assert Xd.shape == Xh.shape == (count * bs, 2 * len(tested) * cube ** 3)
+        assert np.array_equal(Xd, Xh.astype(np.float32))
+        assert np.array_equal(Yd, y.astype(np.float32))
+        assert dev.get_state() == host.get_state()
+        assert host.region_index[0] >= 9 and host.region_index[1] >= 1
+
+
+def test_gather_cubes_explicit_origins_and_errors():
+    """The random-cube form (convolution.py:118-147: origins drawn on the host) against numpy
+    slicing, and the argument checks."""
+    from weather_model_amd import ops, synth
+    files, nv, Z, Y, X = 9, 2, 7, 11, 13
+    vol = synth.uniform(31, (files, nv, Z, Y, X))
+    rng = np.random.default_rng(4)
+    rows, c = 37, (3, 4, 5)
+    org = np.stack([rng.integers(0, files - 4, rows), rng.integers(0, Z - c[0] + 1, rows),
+                    rng.integers(0, Y - c[1] + 1, rows), rng.integers(0, X - c[2] + 1, rows)],
+                   axis=1).astype(np.int32)
+    x1, x2, y = ops.gather_cubes(torch.from_numpy(vol).cuda(), c, 2, 4, rows, origins=org,
+                                 separate=True)
+    for r, (f, z0, y0, x0) in enumerate(org):
+        cut = lambda ff: vol[ff, :, z0:z0 + c[0], y0:y0 + c[1], x0:x0 + c[2]].reshape(-1)   # noqa: E731
+        assert np.array_equal(x1[r].cpu().numpy(), cut(f))
+        assert np.array_equal(x2[r].cpu().numpy(), cut(f + 4))
+        assert np.array_equal(y[r].cpu().numpy(), cut(f + 2))
+    bad = org.copy()
+    bad[3, 0] = files - 2                      # file + 4 leaves the volume
+    with pytest.raises(ValueError, match="leaves the volume"):
+        ops.gather_cubes(torch.from_numpy(vol).cuda(), c, 2, 4, rows, origins=bad)
+    from weather_model_amd import _lib
+    with pytest.raises(_lib.WmError, match="resident files"):
+        ops.gather_cubes(torch.from_numpy(vol).cuda(), (1, 1, 1), 3, 6, 16,
+                         walk={"batch": 16, "length": 4, "index": 0, "region": (0, 0, 0),
+                               "dims": (2, 2, 2)})
+
+
+def test_fit_without_resident_rows_reports_gram_loss():
+    """Rows beyond max_resident_rows are not kept: the loss then comes from the Gram itself
+    (MSE = (Y'Y - 2 b'Z'Y + b'Z'Zb) / nP) and agrees with the row-based loss."""
+    from weather_model_amd.dropin._keras_like import LinearStackModel
+    rng = np.random.default_rng(11)
+    n = 40_000
+    x1 = rng.uniform(size=(n, 2)).astype(np.float32)
+    x2 = rng.uniform(size=(n, 2)).astype(np.float32)
+    y = (0.4 * x1 + 0.5 * x2 + 0.05 * rng.standard_normal((n, 2))).astype(np.float32)
+
+    def batches():
+        for s in range(0, n, 16):
+            yield x1[s:s + 16], x2[s:s + 16], y[s:s + 16]
+    a = LinearStackModel((2,))
+    a.compile(loss="mean_squared_error", metrics=["mae"])
+    ha = a.fit(batches, steps_per_epoch=n // 16, chunk_rows=4096, verbose=0)
+    b = LinearStackModel((2,))
+    b.compile(loss="mean_squared_error", metrics=["mae"])
+    hb = b.fit(batches, steps_per_epoch=n // 16, chunk_rows=4096, max_resident_rows=8192, verbose=0)
+    assert ha.params["metrics_from"] == "rows" and hb.params["metrics_from"].startswith("gram")
+    assert hb.history["loss"][0] == pytest.approx(ha.history["loss"][0], rel=1e-3)
+    assert np.isnan(hb.history["mae"][0]) and ha.history["mae"][0] > 0
+    np.testing.assert_array_equal(a.coefficients[0], b.coefficients[0])
+
+
+def test_single_regression_preloaded_generator_bit_exact(tmp_path):
+    """singleRegression.WeatherGenerator.preload(): 6^3 cubes of 'T' at files i, i+2; i+1 built on the
+    GPU from one read of every file, against the host generator that opens three files per sample
+    (singleRegression.py:251-299,330-340)."""
+    from weather_model_amd.dropin import singleRegression as sr
+    sr = importlib.reload(sr)
+    n_files = 40
+    for k in range(n_files):
+        (tmp_path / f"f{k}").write_text("x")
+    sr.XTRAIN_DATA_PATH = str(tmp_path)
+    files = {sr.getFilePath(i, (n_files,)): fakes.wrf_like_file(
+        700 + i, ['T'], (1, 15, 24, 24), {'T': (-3.0, 5.0)}) for i in range(n_files)}
+    sr.xr = fakes.FakeXarray(files)
+    assert sr.DS_DIM == (1, 3, 2, 2)
+    host, dev = sr.optimizeDataset(), sr.optimizeDataset()
+    dev.preload("cuda")
+    assert dev.device_ready() and not host.device_ready()
+    count = 3 * len(host) + 2
+    gh = host()
+    parts = [next(gh) for _ in range(count)]
+    Xh = np.concatenate([np.concatenate([p[0].reshape(4, -1), p[1].reshape(4, -1)], axis=1)
+                         for p in parts])
+    Yh = np.concatenate([p[2] for p in parts])
+    Xd, Yd = dev.device_rows(count)
+    assert np.array_equal(Xd.cpu().numpy(), Xh.astype(np.float32))
+    assert np.array_equal(Yd.cpu().numpy(), Yh.astype(np.float32))
+    host._advance()                                  # the host generator advances after its yield
+    assert dev.get_state() == host.get_state()

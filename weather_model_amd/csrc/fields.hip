@@ -226,6 +226,85 @@ __global__ __launch_bounds__(BLOCK) void gather_triplets_u32_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Row construction of the regression / Conv3D generators from a RESIDENT volume
+// vol (files, nvars, Z, Y, X): row r takes the (cz,cy,cx) cube of every variable at origin
+// (z0,y0,x0) from the three files f, f + d_end and f + d_mid:
+//     x1[r] = cube(vol[f]),  x2[r] = cube(vol[f + d_end]),  y[r] = cube(vol[f + d_mid])
+// each flattened (var, dz, dy, dx) -- multipleRegression.py:217-257 (x(t), x(t+TIME_SPAN);
+// x(t+TIME_SPAN/2)), singleRegression.py:251-299, convolution.py:118-147.
+// (f, z0, y0, x0) comes from `origins` (int32 x 4 per row: the random cubes of convolution.py,
+// drawn on the host) or, when origins == NULL, from the region walk of WeatherDataGenerator
+// (multipleRegression.py:259-270 / singleRegression.py:330-340) in closed form: batch b = r / bs
+// of the walk that starts at (index0; R0, R1, R2) has
+//     index_b = index0 + b,            f = (index_b % length) * bs + r % bs,
+//     R0_b = index_b / length,  R1_b = R0_{b-1} / dim_z,  R2_b = R1_{b-1} / dim_y   (b >= 1),
+//     origin = (R0_b % dim_z, R1_b % dim_y, R2_b % dim_x)
+// -- the reference's update rule, including that R1 and R2 lag one and two batches behind.
+struct CubeWalk {
+    long long length, index0, r0, r1, r2;
+    int bs, dim_z, dim_y, dim_x;
+};
+
+__device__ __forceinline__ long long walk_r0(const CubeWalk &w, long long b)
+{
+    return b <= 0 ? w.r0 : (w.index0 + b) / w.length;
+}
+__device__ __forceinline__ long long walk_r1(const CubeWalk &w, long long b)
+{
+    return b <= 0 ? w.r1 : walk_r0(w, b - 1) / w.dim_z;
+}
+__device__ __forceinline__ long long walk_r2(const CubeWalk &w, long long b)
+{
+    return b <= 0 ? w.r2 : walk_r1(w, b - 1) / w.dim_y;
+}
+
+__global__ __launch_bounds__(BLOCK) void gather_cubes_kernel(
+    const float *__restrict__ vol, int files, int nvars, int Z, int Y, int X, int cz, int cy,
+    int cx, int d_mid, int d_end, const int *__restrict__ origins, long long rows, CubeWalk w,
+    float *__restrict__ x1out, float *__restrict__ x2out, long long xstride,
+    float *__restrict__ yout)
+{
+    const int p = nvars * cz * cy * cx;
+    const long long total = rows * p;
+    const long long fplane = (long long)nvars * Z * Y * X;
+    const int dmax = d_mid > d_end ? d_mid : d_end;
+    for (long long e = (long long)blockIdx.x * BLOCK + threadIdx.x; e < total;
+         e += (long long)gridDim.x * BLOCK) {
+        const long long r = e / p;
+        int q = (int)(e - r * p);
+        long long f;
+        int z0, y0, x0;
+        if (origins) {
+            f = origins[4 * r];
+            z0 = origins[4 * r + 1];
+            y0 = origins[4 * r + 2];
+            x0 = origins[4 * r + 3];
+        } else {
+            const long long b = r / w.bs;
+            f = ((w.index0 + b) % w.length) * w.bs + (r - b * w.bs);
+            z0 = (int)(walk_r0(w, b) % w.dim_z);
+            y0 = (int)(walk_r1(w, b) % w.dim_y);
+            x0 = (int)(walk_r2(w, b) % w.dim_x);
+        }
+        // the host validated the ranges; clamping keeps a bad origin from faulting the GPU
+        f = max(0ll, min(f, (long long)files - 1 - dmax));
+        z0 = max(0, min(z0, Z - cz));
+        y0 = max(0, min(y0, Y - cy));
+        x0 = max(0, min(x0, X - cx));
+        const int ix = q % cx; q /= cx;
+        const int iy = q % cy; q /= cy;
+        const int iz = q % cz;
+        const int v = q / cz;
+        const float *src = vol + f * fplane +
+                           (((long long)v * Z + z0 + iz) * Y + y0 + iy) * X + x0 + ix;
+        const long long o = e - r * p;
+        x1out[r * xstride + o] = src[0];
+        x2out[r * xstride + o] = src[(long long)d_end * fplane];
+        yout[r * p + o] = src[(long long)d_mid * fplane];
+    }
+}
+
 int stream_grid(long long work_items)
 {
     long long g = (work_items + BLOCK - 1) / BLOCK;
@@ -333,5 +412,45 @@ extern "C" int wm_gather_triplets_f32(const float *vol, const int64_t *idx, int6
                        (hipStream_t)stream, vol, (const long long *)idx, (long long)idx0, xout,
                        yout, (long long)B, V, Z, Y, X, St, Sz, Sy, Sx, time_offset, d_mid, d_end);
     WM_LAUNCH_CHECK("gather_triplets_kernel");
+    return WM_OK;
+}
+
+extern "C" int wm_gather_cubes_f32(const float *vol, int files, int nvars, int Z, int Y, int X,
+                                   int cz, int cy, int cx, int d_mid, int d_end,
+                                   const int32_t *origins, int64_t rows, int batch, int64_t length,
+                                   int64_t index0, int64_t r0, int64_t r1, int64_t r2, int dim_z,
+                                   int dim_y, int dim_x, float *x1out, float *x2out,
+                                   int64_t xstride, float *yout, void *stream)
+{
+    WM_REQUIRE(vol && x1out && x2out && yout, WM_ERR_INVALID, "wm_gather_cubes_f32: null pointer");
+    WM_REQUIRE(files > 0 && nvars > 0 && Z > 0 && Y > 0 && X > 0, WM_ERR_INVALID,
+               "wm_gather_cubes_f32: bad volume shape");
+    WM_REQUIRE(cz > 0 && cy > 0 && cx > 0 && cz <= Z && cy <= Y && cx <= X, WM_ERR_INVALID,
+               "wm_gather_cubes_f32: cube (%d,%d,%d) outside the (%d,%d,%d) grid", cz, cy, cx, Z,
+               Y, X);
+    WM_REQUIRE(d_mid >= 0 && d_end >= 0 && d_mid < files && d_end < files, WM_ERR_INVALID,
+               "wm_gather_cubes_f32: file offsets (%d, %d) outside %d files", d_mid, d_end, files);
+    const long long p = (long long)nvars * cz * cy * cx;
+    WM_REQUIRE(rows >= 0 && p < (1ll << 31) && xstride >= p, WM_ERR_INVALID,
+               "wm_gather_cubes_f32: bad row count or row stride");
+    if (rows == 0) return WM_OK;
+    CubeWalk w = {length, index0, r0, r1, r2, batch, dim_z, dim_y, dim_x};
+    if (!origins) {
+        WM_REQUIRE(batch > 0 && length > 0 && index0 >= 0 && r0 >= 0 && r1 >= 0 && r2 >= 0,
+                   WM_ERR_INVALID, "wm_gather_cubes_f32: bad walk state");
+        WM_REQUIRE(dim_z > 0 && dim_y > 0 && dim_x > 0 && dim_z - 1 + cz <= Z &&
+                       dim_y - 1 + cy <= Y && dim_x - 1 + cx <= X,
+                   WM_ERR_INVALID, "wm_gather_cubes_f32: walk region (%d,%d,%d) + cube leaves the grid",
+                   dim_z, dim_y, dim_x);
+        const int dmax = d_mid > d_end ? d_mid : d_end;
+        WM_REQUIRE((length - 1) * batch + batch - 1 + dmax < files, WM_ERR_INVALID,
+                   "wm_gather_cubes_f32: walk of %lld batches of %d files + offset %d needs more "
+                   "than the %d resident files", (long long)length, batch, dmax, files);
+    }
+    WM_REQUIRE(wm_num_cus() > 0, WM_ERR_NO_DEVICE, "wm_gather_cubes_f32: no HIP device");
+    hipLaunchKernelGGL(gather_cubes_kernel, dim3(stream_grid(rows * p)), dim3(BLOCK), 0,
+                       (hipStream_t)stream, vol, files, nvars, Z, Y, X, cz, cy, cx, d_mid, d_end,
+                       origins, (long long)rows, w, x1out, x2out, (long long)xstride, yout);
+    WM_LAUNCH_CHECK("gather_cubes_kernel");
     return WM_OK;
 }

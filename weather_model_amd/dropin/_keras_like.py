@@ -12,10 +12,19 @@ What a caller of the reference sees unchanged: ``compile(...)``, ``fit(dataset, 
 steps_per_epoch=, validation_data=, validation_steps=, batch_size=, callbacks=, verbose=)`` ->
 object with ``.history`` (dict of lists) and ``.epoch`` (list), ``predict([x1, x2])`` -> float32
 ndarray ``(B, prod(input_shape))``, ``evaluate``, ``save``/``export``, ``get_weights`` (the Keras
-variable order: kernel, bias per Dense layer).  What differs: one pass over ``steps_per_epoch``
-batches is the whole fit (the solve is exact, so ``epoch == [0]`` whatever ``epochs`` says -- the
-reference's EarlyStopping(patience=2) would have nothing left to improve), and there is no CPU
-path: without libwm.so and a GPU every compute call raises.
+variable order: kernel, bias per Dense layer).  What differs: the SOLVER.  Epoch e consumes the next
+``steps_per_epoch`` batches of the (never-ending, region-walking) generator exactly as Keras would,
+adds their Gram to the running Gram of all epochs so far and re-solves, so after E epochs the map
+is the least-squares fit over the same ``E * steps_per_epoch`` batches the reference's Adam loop
+would have seen; ``history['loss'][e]`` is the MSE of that epoch's solution on that epoch's rows,
+and ``EarlyStopping(monitor, patience)`` acts on it as in Keras.  ``History.params`` names the
+solver, the ridge used and the parity status so that nobody mistakes the numbers for an Adam
+trajectory.  There is no CPU path: without libwm.so and a GPU every compute call raises.
+
+Rows never have to fit in memory twice: a generator that can rebuild its batches on the GPU from a
+resident volume (``device_rows``: ``wm_gather_cubes_f32``) is streamed chunk by chunk, once for the
+Gram and once for the metrics; host generators are staged through a pinned buffer and their device
+chunks are kept for the metrics pass only up to ``max_resident_rows``.
 
 Parity note: tensorflow/keras are absent from the build container, so nothing here is pinned
 against the reference's own training run ("parity unpinned"); the fit is pinned against float64
@@ -50,11 +59,31 @@ class History:
 
 
 class EarlyStopping:
-    """Accepted for call compatibility (``tf.keras.callbacks.EarlyStopping(monitor='loss',
-    patience=2)``, multipleRegression.py:339); the exact solve leaves it nothing to do."""
+    """``tf.keras.callbacks.EarlyStopping(monitor='loss', patience=2)`` (multipleRegression.py:339,
+    singleRegression.py:498): stop once ``monitor`` has not improved by more than ``min_delta`` for
+    ``patience`` consecutive epochs (minimised quantity)."""
 
-    def __init__(self, monitor="val_loss", patience=0, **kwargs):
-        self.monitor, self.patience, self.kwargs = monitor, patience, kwargs
+    def __init__(self, monitor="val_loss", patience=0, min_delta=0.0, **kwargs):
+        self.monitor, self.patience, self.min_delta = monitor, int(patience), abs(float(min_delta))
+        self.kwargs = kwargs
+        self.best, self.wait, self.stopped_epoch = float("inf"), 0, 0
+
+    def reset(self):
+        self.best, self.wait, self.stopped_epoch = float("inf"), 0, 0
+
+    def update(self, epoch, logs) -> bool:
+        """True when training should stop after this epoch."""
+        value = logs.get(self.monitor)
+        if value is None or value != value:
+            return False
+        if value < self.best - self.min_delta:
+            self.best, self.wait = value, 0
+            return False
+        self.wait += 1
+        if self.wait >= self.patience:
+            self.stopped_epoch = epoch
+            return True
+        return False
 
 
 def _metric_names(metrics):
@@ -110,7 +139,7 @@ def _batches(source, steps):
 class _RowStore:
     """Rows staged through one pinned host buffer into resident device chunks."""
 
-    def __init__(self, F, P, device, chunk_rows):
+    def __init__(self, F, P, device, chunk_rows, on_chunk=None, max_resident_rows=None):
         self.F, self.P, self.device = F, P, device
         self.chunk_rows = int(chunk_rows)
         self.host = torch.empty((self.chunk_rows, F + P), dtype=torch.float32,
@@ -118,6 +147,9 @@ class _RowStore:
         self.fill = 0
         self.chunks: list[tuple[torch.Tensor, torch.Tensor]] = []
         self.rows = 0
+        self.on_chunk = on_chunk                      # called with (X, Y) as each chunk lands
+        self.max_resident_rows = max_resident_rows    # beyond it chunks are dropped after on_chunk
+        self.dropped = False
 
     def add(self, X, Y):
         if X.shape[1] != self.F or Y.shape[1] != self.P:
@@ -141,8 +173,14 @@ class _RowStore:
         X = dev[:, :self.F].contiguous()
         Y = dev[:, self.F:].contiguous()
         torch.cuda.current_stream(self.device).synchronize()     # host buffer is reused next
-        self.chunks.append((X, Y))
+        if self.on_chunk is not None:
+            self.on_chunk(X, Y)
         self.rows += self.fill
+        if self.max_resident_rows is not None and self.rows > self.max_resident_rows:
+            self.dropped = True
+            self.chunks.clear()
+        elif not self.dropped:
+            self.chunks.append((X, Y))
         self.fill = 0
 
 
@@ -210,74 +248,154 @@ class LinearStackModel:
     # ------------------------------------------------------------------ fit
     def _metrics(self, chunks, prefix=""):
         """loss + compiled metrics of the current beta over resident row chunks."""
-        keys = ["loss"] + self._metric_keys
-        sums = {k: torch.zeros((), device=self.device, dtype=torch.float64) for k in keys}
-        count = 0
+        sums = self._new_sums()
         for X, Y in chunks:
-            pred = ops.linear_predict(X, self.beta).double()
-            y = Y.double()
-            d = pred - y
-            sums["loss"] += (d * d).sum()
-            if "mean_squared_error" in sums:
-                sums["mean_squared_error"] += (d * d).sum()
-            if "mae" in sums:
-                sums["mae"] += d.abs().sum()
-            if "msle" in sums:
-                e = torch.log1p(pred.clamp_min(_MSLE_EPS)) - torch.log1p(y.clamp_min(_MSLE_EPS))
-                sums["msle"] += (e * e).sum()
-            count += Y.numel()
-        tot = torch.stack([sums[k] for k in keys])
-        cnt = torch.tensor([float(count)], device=self.device, dtype=torch.float64)
+            self._sums_of(X, Y, sums)
+        return self._finish_sums(sums, prefix)
+
+    def _sums_of(self, X, Y, sums):
+        """Add the residual sums of the current beta over one resident chunk."""
+        pred = ops.linear_predict(X, self.beta).double()
+        yv = Y.double()
+        d = pred - yv
+        sums["loss"] += (d * d).sum()
+        if "mean_squared_error" in sums:
+            sums["mean_squared_error"] += (d * d).sum()
+        if "mae" in sums:
+            sums["mae"] += d.abs().sum()
+        if "msle" in sums:
+            e = torch.log1p(pred.clamp_min(_MSLE_EPS)) - torch.log1p(yv.clamp_min(_MSLE_EPS))
+            sums["msle"] += (e * e).sum()
+        sums["_count"] += float(Y.numel())
+
+    def _finish_sums(self, sums, prefix=""):
+        keys = ["loss"] + self._metric_keys
+        both = torch.stack([sums[k] for k in keys] + [sums["_count"]])
         if dp.world() > 1:
-            both = torch.cat((tot, cnt))
             dp.allreduce_sum_(both)
-            tot, cnt = both[:-1], both[-1:]
-        vals = (tot / cnt.clamp_min(1.0)).cpu().tolist()
+        vals = (both[:-1] / both[-1].clamp_min(1.0)).cpu().tolist()
         return {prefix + k: float(v) for k, v in zip(keys, vals)}
+
+    def _new_sums(self):
+        keys = ["loss"] + self._metric_keys + ["_count"]
+        return {k: torch.zeros((), device=self.device, dtype=torch.float64) for k in keys}
+
+    def _loss_from_gram(self, acc):
+        """MSE of the current beta over the rows summarised by ``acc`` (the Gram of [X|1|Y]):
+        (tr Y'Y - 2 tr beta'Z'Y + tr beta'Z'Z beta) / (n P).  Used only when the rows themselves are
+        gone; it inherits the float32 rounding of the Gram products (~1e-7 of tr Y'Y)."""
+        F1 = self.F + 1
+        A, B, C = acc[:F1, :F1], acc[:F1, F1:], acc[F1:, F1:]
+        sse = torch.trace(C) - 2.0 * (self.beta * B).sum() + (self.beta * (A @ self.beta)).sum()
+        n = acc[self.F, self.F]
+        return float((sse.clamp_min(0.0) / (n * self.P).clamp_min(1.0)).item())
+
+    def _stream(self, source, steps, chunk_rows, on_chunk, keep_rows_up_to):
+        """Feed ``steps`` batches of ``source`` to ``on_chunk(X, Y)`` in device chunks.  Returns a
+        callable that replays the same chunks (for the metrics pass) or None if they are gone."""
+        if self.device.type == "cuda" and hasattr(source, "device_rows") and \
+                getattr(source, "device_ready", lambda: False)():
+            if steps is None:
+                raise ValueError("steps_per_epoch / validation_steps is required for a generator")
+            per = max(1, int(chunk_rows) // max(1, int(source.rows_per_batch())))
+            state = source.get_state()
+
+            def run(fn):
+                left = int(steps)
+                while left > 0:
+                    k = min(per, left)
+                    X, Y = source.device_rows(k, self.device)
+                    fn(X, Y)
+                    left -= k
+            run(on_chunk)
+            end_state = source.get_state()
+
+            def replay(fn):
+                source.set_state(state)
+                run(fn)
+                source.set_state(end_state)
+            return replay
+        store = _RowStore(self.F, self.P, self.device, chunk_rows, on_chunk, keep_rows_up_to)
+        for batch in _batches(source, steps):
+            store.add(*_as_rows(*batch))
+        store.flush()
+        if store.dropped:
+            return None
+        chunks = store.chunks
+
+        def replay(fn):
+            for X, Y in chunks:
+                fn(X, Y)
+        return replay
 
     def fit(self, x=None, y=None, batch_size=None, epochs=1, verbose=1, callbacks=None,
             validation_split=0.0, validation_data=None, shuffle=True, steps_per_epoch=None,
-            validation_steps=None, chunk_rows=1 << 18, ridge=None, **kwargs):
-        """Least-squares fit over ``steps_per_epoch`` batches of ``x`` (see module docstring).
+            validation_steps=None, chunk_rows=1 << 18, ridge=None,
+            max_resident_rows=1 << 26, **kwargs):
+        """Least-squares fit, one Gram pass + one solve per epoch (see the module docstring).
 
-        ``x`` is any source ``_batches`` understands; ``(x, y)`` arrays are also accepted with
-        ``x = [x1, x2]``.  Under an initialised ``torch.distributed`` group every rank feeds its own
-        batches and the partial Grams are summed by one all-reduce."""
-        if y is not None:
-            x1, x2 = x
-            source = (x1, x2, y)
-        else:
-            source = x
-        store = _RowStore(self.F, self.P, self.device, chunk_rows)
-        for batch in _batches(source, steps_per_epoch):
-            store.add(*_as_rows(*batch))
-        store.flush()
+        ``x`` is any source ``_batches`` understands, or a generator object with ``device_rows``;
+        ``(x, y)`` arrays are also accepted with ``x = [x1, x2]``.  Under an initialised
+        ``torch.distributed`` group every rank feeds its own batches and the partial Grams are
+        summed by one all-reduce per epoch."""
+        source = (x[0], x[1], y) if y is not None else x
+        fixed_rows = isinstance(source, (tuple, list)) or \
+            (hasattr(source, "__len__") and hasattr(source, "__getitem__") and not callable(source))
+        epochs = max(1, int(epochs))
         D = self.F + 1 + self.P
-        acc = torch.zeros((D, D), device=self.device, dtype=torch.float64)
-        for X, Y in store.chunks:
-            ops.gram(X, Y, acc)
-        dp.reduce_gram_(acc)
-        n_total = float(acc[self.F, self.F].item())            # sum of 1*1 = global row count
-        if n_total < 1:
-            raise ValueError("fit received no rows")
-        self.rows_seen = int(n_total)
-        self.beta, self.ridge = self._solve(acc, ridge)
+        total = torch.zeros((D, D), device=self.device, dtype=torch.float64)
+        acc_e = torch.zeros_like(total)
         hist = History(self)
-        hist.params = {"epochs": epochs, "steps": steps_per_epoch, "verbose": verbose}
-        logs = self._metrics(store.chunks)
-        if validation_data is not None:
-            vstore = _RowStore(self.F, self.P, self.device, chunk_rows)
-            for batch in _batches(validation_data, validation_steps):
-                vstore.add(*_as_rows(*batch))
-            vstore.flush()
-            logs.update(self._metrics(vstore.chunks, prefix="val_"))
-        for k, v in logs.items():
-            hist.history[k] = [v]
-        hist.epoch = [0]
-        if verbose and dp.rank() == 0:
-            shown = " - ".join(f"{k}: {v:.6g}" for k, v in logs.items())
-            print(f"Epoch 1/{epochs} (closed-form least squares over {self.rows_seen} rows)\n"
-                  f"{steps_per_epoch if steps_per_epoch is not None else '?'} steps - {shown}")
+        stoppers = [c for c in (callbacks or []) if isinstance(c, EarlyStopping)]
+        for c in stoppers:
+            c.reset()
+        replay = None
+        self.rows_seen = 0
+        for epoch in range(epochs):
+            if not (fixed_rows and epoch > 0):
+                # the same arrays every epoch add nothing to a least-squares fit: their Gram is
+                # taken once; a generator yields NEW batches every epoch
+                acc_e.zero_()
+                replay = self._stream(source, steps_per_epoch, chunk_rows,
+                                      lambda X, Y: ops.gram(X, Y, acc_e), max_resident_rows)
+                dp.reduce_gram_(acc_e)
+                n_epoch = float(acc_e[self.F, self.F].item())     # sum of 1*1 = global row count
+                if n_epoch < 1:
+                    raise ValueError("fit received no rows")
+                total += acc_e
+                self.rows_seen += int(n_epoch)
+                self.beta, self.ridge = self._solve(total, ridge)
+            if replay is not None:
+                sums = self._new_sums()
+                replay(lambda X, Y: self._sums_of(X, Y, sums))
+                logs = self._finish_sums(sums)
+            else:
+                logs = {"loss": self._loss_from_gram(acc_e)}
+                logs.update({k: float("nan") for k in self._metric_keys})
+                if "mean_squared_error" in logs:
+                    logs["mean_squared_error"] = logs["loss"]
+            if validation_data is not None:
+                sums = self._new_sums()
+                self._stream(validation_data, validation_steps, chunk_rows,
+                             lambda X, Y: self._sums_of(X, Y, sums), 0)
+                logs.update(self._finish_sums(sums, prefix="val_"))
+            for k, v in logs.items():
+                hist.history.setdefault(k, []).append(v)
+            hist.epoch.append(epoch)
+            if verbose and dp.rank() == 0:
+                shown = " - ".join(f"{k}: {v:.6g}" for k, v in logs.items())
+                print(f"Epoch {epoch + 1}/{epochs} (closed-form least squares over "
+                      f"{self.rows_seen} rows so far; parity unpinned)\n"
+                      f"{steps_per_epoch if steps_per_epoch is not None else '?'} steps - {shown}")
+            if any(c.update(epoch, logs) for c in stoppers):
+                break
+        hist.params = {"epochs": epochs, "steps": steps_per_epoch, "verbose": verbose,
+                       "solver": "closed-form ordinary least squares on the running Gram of all "
+                                 "epochs (not an Adam trajectory)",
+                       "ridge": self.ridge, "rows": self.rows_seen,
+                       "metrics_from": "rows" if replay is not None else "gram (rows not kept)",
+                       "parity": "unpinned: keras/tensorflow absent, no reference fixture; pinned "
+                                 "against float64 numpy.linalg.lstsq on the same rows"}
         self.history = hist
         return hist
 

@@ -86,9 +86,11 @@ class DataGenerator:
     """Random INPUT_SHAPE cubes: x1 at time t, x2 at t+4, y at t+2, BATCH_SIZE per batch
     (:107-153).  Shapes: x (B, n_vars, Z, Y, X), y (B, n_vars, Z*Y*X)."""
 
-    def __init__(self, data):
+    def __init__(self, data, device=None):
         self.index = 0
         self.data = data
+        self.device = device          # not in the reference: "cuda" -> batches gathered on the GPU
+        self._vol = None
         first = self.data[DATA_VARIABLES[0]]
         self.data_shape = (len(first) - 4,
                            len(first[0][0]) - INPUT_SHAPE[2],
@@ -118,6 +120,36 @@ class DataGenerator:
         return (np.stack(starts), np.stack(ends),
                 np.reshape(batch_y, (batch_y.shape[0], batch_y.shape[1], -1)))
 
+    def device_volume(self):
+        """(files, n_vars, Z, Y, X) float32 copy of ``data`` on ``self.device``, built once."""
+        import torch
+        if self._vol is None:
+            host = np.stack([np.asarray(self.data[v], dtype=np.float32)[:, 0]
+                             for v in DATA_VARIABLES], axis=1)
+            self._vol = torch.from_numpy(np.ascontiguousarray(host)).to(self.device)
+        return self._vol
+
+    def device_getitem(self):
+        """``__getitem__`` with the cubes cut on the GPU (wm_gather_cubes_f32 with explicit
+        origins): the SAME ``random.randint`` draws in the same order, so a seeded run yields bit
+        for bit the batches of the host path -- as device tensors."""
+        from weather_model_amd import ops
+        n_t, n_z, n_y, n_x = self.data_shape
+        origins = np.empty((BATCH_SIZE, 4), dtype=np.int32)
+        for b in range(BATCH_SIZE):
+            origins[b] = ((self.index // (n_x * n_y * n_z)) % n_t,
+                          (self.index // (n_x * n_y)) % n_z,
+                          (self.index // n_x) % n_y,
+                          self.index % n_x)
+            self.index += random.randint(0, self.__len__() - 1)
+            self.index %= self.__len__()
+        cube = (INPUT_SHAPE[2], INPUT_SHAPE[1], INPUT_SHAPE[0])
+        x1, x2, y = ops.gather_cubes(self.device_volume(), cube, 2, 4, BATCH_SIZE,
+                                     origins=origins, separate=True)
+        nv = len(DATA_VARIABLES)
+        return (x1.view(BATCH_SIZE, nv, *cube), x2.view(BATCH_SIZE, nv, *cube),
+                y.view(BATCH_SIZE, nv, -1))
+
     def get_batch(self, var, column, row, height, time):
         return self.data[var][time][0][height: height + INPUT_SHAPE[2],
                                        row: row + INPUT_SHAPE[1],
@@ -125,7 +157,7 @@ class DataGenerator:
 
     def __call__(self):
         while True:
-            yield self.__getitem__()
+            yield self.device_getitem() if self.device is not None else self.__getitem__()
             self.index = random.randint(0, self.__len__() - 1)
             self.index %= self.__len__()
 

@@ -212,6 +212,51 @@ class WeatherDataGenerator:
             self._advance()
         return tuple(np.concatenate([p[k] for p in parts], axis=0) for k in range(3))
 
+    # -------------------------------------------------------------- device-side rows (row a9)
+    # Not in the reference: the same batches built on the GPU from a resident copy of all_data
+    # (wm_gather_cubes_f32 evaluates the region walk above in closed form), so ``fit`` never sees a
+    # host row.  ``LinearStackModel.fit`` uses this protocol when it finds it.
+    def rows_per_batch(self):
+        return BATCH_SIZE[self.iteration]
+
+    def get_state(self):
+        return self.index, tuple(self.region_index)
+
+    def set_state(self, state):
+        self.index, self.region_index = state[0], tuple(state[1])
+
+    def device_ready(self):
+        import torch
+        return bool(LOAD_DATA and getattr(self, "all_data", None)) and torch.cuda.is_available()
+
+    def device_volume(self, device="cuda"):
+        """(files, n_tested_vars, Z, Y, X) float32 on the GPU, files from ``start_index`` on; built
+        once per generator."""
+        import torch
+        vol = getattr(self, "_vol", None)
+        if vol is None or vol.device != torch.device(device):
+            tested = [d for d in DATA_VARS if VARIABLE_TEST[self.iteration][d]]
+            host = np.stack([np.stack([np.asarray(f[d][0], dtype=np.float32) for d in tested])
+                             for f in self.all_data])
+            vol = torch.from_numpy(np.ascontiguousarray(host)).to(device)
+            self._vol = vol
+        return vol
+
+    def device_rows(self, count, device="cuda"):
+        """The next ``count`` batches as device tensors X (rows, 2p) = [x1 | x2], Y (rows, p) --
+        bit for bit the values of ``rows(count)`` -- and the generator advanced past them."""
+        from weather_model_amd import ops
+        c = CUBE_SIZE[self.iteration]
+        bs = BATCH_SIZE[self.iteration]
+        vol = self.device_volume(device)
+        walk = {"batch": bs, "length": self.__len__(), "index": self.index,
+                "region": self.region_index, "dims": tuple(self.data_dim[1:4])}
+        X, Y = ops.gather_cubes(vol, (c, c, c), TIME_SPAN // 2, TIME_SPAN, int(count) * bs,
+                                walk=walk)
+        for _ in range(int(count)):
+            self._advance()
+        return X, Y
+
 
 def create_model(input_shape):
     """start/end inputs -> Flatten -> Concatenate -> Dense(2p, linear) 'layer1' -> Dense(2p,

@@ -455,6 +455,53 @@ def gather_triplets(vol, shape, indices=None, first=0, count=None, time_offset=0
     return xout, yout
 
 
+def gather_cubes(vol, cube, d_mid, d_end, rows, origins=None, walk=None, separate=False):
+    """Rows of the regression / Conv3D generators from a resident (files, nvars, Z, Y, X) volume
+    (``wm_gather_cubes_f32``).  ``cube`` = (cz, cy, cx).  Either ``origins`` -- an int32 (rows, 4)
+    tensor/array of (file, z0, y0, x0) -- or ``walk`` = dict(batch, length, index, region=(r0,r1,r2),
+    dims=(dim_z, dim_y, dim_x)), the generator state at the first batch.
+    Returns (X (rows, 2p), Y (rows, p)), or (x1 (rows, p), x2 (rows, p), Y) with ``separate``."""
+    vol = _req(vol, "volume")
+    if vol.dim() != 5:
+        raise ValueError(f"volume must be (files, nvars, Z, Y, X), got {tuple(vol.shape)}")
+    files, nvars, Z, Y, X = vol.shape
+    cz, cy, cx = (int(v) for v in cube)
+    p = nvars * cz * cy * cx
+    rows = int(rows)
+    dev = vol.device
+    if separate:
+        x1 = torch.empty((rows, p), device=dev, dtype=torch.float32)
+        x2 = torch.empty((rows, p), device=dev, dtype=torch.float32)
+        a, b, stride = x1, x2, p
+    else:
+        Xo = torch.empty((rows, 2 * p), device=dev, dtype=torch.float32)
+        a, b, stride = Xo, Xo[:, p:], 2 * p
+    Yo = torch.empty((rows, p), device=dev, dtype=torch.float32)
+    if rows > 0:
+        dmax = max(int(d_mid), int(d_end))
+        if origins is not None:
+            o = torch.as_tensor(origins)
+            if o.shape != (rows, 4):
+                raise ValueError(f"origins must be (rows, 4), got {tuple(o.shape)}")
+            lo = o.min(dim=0).values.tolist()
+            hi = o.max(dim=0).values.tolist()
+            if min(lo) < 0 or hi[0] + dmax >= files or hi[1] + cz > Z or hi[2] + cy > Y or \
+                    hi[3] + cx > X:
+                raise ValueError("a cube origin leaves the volume")
+            o = o.to(device=dev, dtype=torch.int32).contiguous()
+            args = (o.data_ptr(), rows, 1, 1, 0, 0, 0, 0, 1, 1, 1)
+        else:
+            r0, r1, r2 = (int(v) for v in walk["region"])
+            dz, dy, dx = (int(v) for v in walk["dims"])
+            args = (0, rows, int(walk["batch"]), int(walk["length"]), int(walk["index"]), r0, r1, r2,
+                    dz, dy, dx)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().wm_gather_cubes_f32(
+                vol.data_ptr(), files, nvars, Z, Y, X, cz, cy, cx, int(d_mid), int(d_end), *args,
+                a.data_ptr(), b.data_ptr(), stride, Yo.data_ptr(), _stream()))
+    return (x1, x2, Yo) if separate else (Xo, Yo)
+
+
 # --------------------------------------------------------------------------- synthetic data
 
 def synth_uniform(shape, seed, lo=0.0, hi=1.0, offset=0, device="cuda"):
