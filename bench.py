@@ -732,6 +732,58 @@ def run_conv32(steps, warmup, rank, world, cpu_base, N=8, C=32, H=721, W=1440):
                          "TFLOPs": {k: flops_pass / (v * 1e-3) / 1e12 for k, v in ms.items()}}}
 
 
+def run_conv32x3(steps, warmup, rank, world, cpu_base, N=8, C=32, H=721, W=1440, L=3):
+    """BASELINE configs[3] read literally, as a MODEL: L = 3 layers of Conv2d(32 -> 32, 3x3) + ReLU
+    on (N, 32, 721, 1440) per GPU, forward + backward (weight, bias gradients of every layer,
+    input gradients between the layers with the ReLU mask fused into the backward-data store), one
+    flat gradient all-reduce of 3 x 9248 floats under data parallelism."""
+    from weather_model_amd import ops
+    from weather_model_amd.stack import ConvStack
+    x = ops.synth_uniform((N, C, H, W), seed=40, offset=rank * N * C * H * W)
+    ws = [ops.synth_uniform((C, C, 3, 3), seed=41 + l, lo=-1.0 / 17, hi=1.0 / 17) for l in range(L)]
+    bs = [ops.synth_uniform((C,), seed=45 + l, lo=-0.05, hi=0.05) for l in range(L)]
+    st = ConvStack(ws, bs, x.shape)
+    oshape = st.shapes[-1]
+    gout = ops.synth_uniform(oshape, seed=49, lo=-1.0, hi=1.0,
+                             offset=rank * int(np.prod(oshape)))
+    gwork = torch.empty_like(gout)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+
+    def step(i, timed):
+        if timed and i == warmup:
+            ev[0].record()
+        gwork.copy_(gout)                  # the upstream gradient of this step (masked in place)
+        st.step_grads(x, gwork)
+        if timed and i == warmup + steps - 1:
+            ev[1].record()
+
+    total = timed_steps(step, steps, warmup, world)
+    ms = ev[0].elapsed_time(ev[1]) / steps
+    # 2 C C 9 flop per output position: L forward passes, L weight-gradient passes over the same
+    # positions, L - 1 backward-data passes (over the INPUT positions of layers 2..L)
+    flops = 0.0
+    for l in range(1, L + 1):
+        out_pos = float(np.prod(st.shapes[l])) / C
+        flops += 2.0 * C * C * 9 * out_pos * 2
+        if l > 1:
+            flops += 2.0 * C * C * 9 * out_pos          # executed over the outputs of layer l
+    ach = flops / (ms * 1e-3) / 1e12
+    clipped = float((st.h[L] == 0).float().mean())
+    return {"value": N * H * W * world * steps / total, "unit": "grid-pts/s",
+            "ms_per_step": total / steps * 1e3, "step_kernels_ms": ms,
+            "relu_clipped_fraction_last_layer": clipped,
+            "grad_floats_all_reduced": int(st.flat_grads.numel()),
+            "config": {"workload": f"{L} x [Conv2d({C}->{C}, 3x3) + ReLU] forward + backward on "
+                                   f"({N},{C},{H},{W}) per GPU, ReLU masks fused, one flat gradient "
+                                   f"all-reduce"},
+            "roofline": {"bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF,
+                         "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF, "traffic": None,
+                         "kernel": "conv3d_fwd_rows_kernel x3 + conv3d_bwd_wb_rows_kernel x3 + "
+                                   "conv3d_bwd_data_rows_kernel x2 (+ mask, copy, finalize launches "
+                                   "inside the bracket)",
+                         "algorithmic_flops_per_step": flops}}
+
+
 # ------------------------------------------------------------------------------ Conv3D model
 def run_conv3d_model(steps, warmup, batch=16):
     """the reference's Conv3D network (convolution.py:156-180) at its own shapes,
@@ -872,8 +924,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="all", choices=["all", "gram16", "conv3x3", "gram64", "model32", "fields", "conv32", "conv3d_model",
-                             "plumbing"])
+    ap.add_argument("--workload", default="all", choices=["all", "gram16", "conv3x3", "gram64", "model32", "fields", "conv32", "conv32x3",
+                             "conv3d_model", "plumbing"])
     ap.add_argument("--rows", type=int, default=100_000_000, help="rows per GPU (gram16)")
     ap.add_argument("--rows64", type=int, default=1_250_000_000,
                     help="rows per GPU of the F=64 workload (config 5: 1e10 rows / 8 GPUs)")
@@ -982,6 +1034,17 @@ def main():
                         "kernel_ms": cres["kernel_ms"]})
         else:
             out.setdefault("also", {})["conv32"] = cres
+    if args.workload in ("all", "conv32x3"):
+        k3 = args.steps if args.workload == "conv32x3" else min(args.steps, 8)
+        w3 = args.warmup if args.workload == "conv32x3" else min(args.warmup, 2)
+        sres = run_conv32x3(k3, w3, rank, world, cpu_base)
+        sres["steps"], sres["warmup"] = k3, w3
+        if args.workload == "conv32x3":
+            out.update({"metric": "grid-pts/s 3-layer conv32 model fwd+bwd", "unit": "grid-pts/s",
+                        "value": sres["value"], "ms_per_step": sres["ms_per_step"],
+                        "roofline": sres["roofline"], "config": sres["config"]})
+        else:
+            out.setdefault("also", {})["conv32x3"] = sres
     if args.workload in ("all", "fields"):
         fres = run_fields(args.steps, args.warmup, rank, world, cpu_base)
         if args.workload == "fields":

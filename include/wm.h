@@ -61,6 +61,14 @@ int wm_conv2d_bwd_data_f32(const float *gy, const float *w, float *gx,
                            int N, int Cin, int H, int W, int Cout, int kH, int kW,
                            void *stream);
 
+/* The same with the backward of the nn.ReLU that FOLLOWS the layer below (newConvolution.py:150,153,
+ * 156,159 under loss.backward(), :184) fused in: ymask is that layer's post-ReLU output, shaped like
+ * gx, and gx = ymask > 0 ? gx : 0.  wm_relu_mask_f32 is the stand-alone form (in place). */
+int wm_conv2d_bwd_data_relu_f32(const float *gy, const float *w, const float *ymask, float *gx,
+                                int N, int Cin, int H, int W, int Cout, int kH, int kW,
+                                void *stream);
+int wm_relu_mask_f32(float *gx, const float *ymask, int64_t n, void *stream);
+
 /* Replaces the grad_weight and grad_bias legs (newConvolution.py:184):
  *   gw[o,c,kh,kw] = sum_{n,i,j} gy[n,o,i,j] x[n,c,i+kh,j+kw],  gb[o] = sum_{n,i,j} gy[n,o,i,j].
  * gb may be NULL.  Partial sums go through `workspace` (float64) and are combined in a fixed
@@ -101,6 +109,9 @@ int wm_conv3d_fwd_f32(const float *x, const float *w, const float *b, float *y,
 int wm_conv3d_bwd_data_f32(const float *gy, const float *w, float *gx,
                            int B, int Cin, int D, int H, int W, int Cout, int kD, int kH, int kW,
                            void *stream);
+int wm_conv3d_bwd_data_relu_f32(const float *gy, const float *w, const float *ymask, float *gx,
+                                int B, int Cin, int D, int H, int W, int Cout, int kD, int kH,
+                                int kW, void *stream);   /* gx = ymask > 0 ? gx : 0, as above */
 size_t wm_conv3d_bwd_wb_workspace_bytes(int B, int Cin, int D, int H, int W, int Cout,
                                         int kD, int kH, int kW);
 int wm_conv3d_bwd_wb_f32(const float *x, const float *gy, float *gw, float *gb,

@@ -1228,6 +1228,45 @@ extern "C" int wm_conv2d_bwd_data_f32(const float *gy, const float *w, float *gx
     return WM_OK;
 }
 
+// the same with the ReLU backward of the layer below fused in: gx = ymask > 0 ? gx : 0, ymask = that
+// layer's (post-ReLU) output, shaped like gx.  Multi-channel shapes fuse it into the row kernel's
+// store; the others apply it in a second element-wise launch.
+extern "C" int wm_relu_mask_f32(float *gx, const float *ymask, int64_t n, void *stream);
+
+extern "C" int wm_conv2d_bwd_data_relu_f32(const float *gy, const float *w, const float *ymask,
+                                           float *gx, int N, int Cin, int H, int W, int Cout, int kH,
+                                           int kW, void *stream)
+{
+    WM_REQUIRE(gy && w && gx && ymask, WM_ERR_INVALID, "wm_conv2d_bwd_data_relu_f32: null pointer");
+    if (int rc = check_dims(N, Cin, H, W, Cout, kH, kW)) return rc;
+    if (mfma_shape(N, Cin, H, W, Cout, kH, kW))
+        return wm_conv3d_bwd_data_relu_f32(gy, w, ymask, gx, N, Cin, 1, H, W, Cout, 1, kH, kW,
+                                           stream);
+    if (int rc = wm_conv2d_bwd_data_f32(gy, w, gx, N, Cin, H, W, Cout, kH, kW, stream)) return rc;
+    return wm_relu_mask_f32(gx, ymask, (int64_t)N * Cin * H * W, stream);
+}
+
+// gx = ymask > 0 ? gx : 0 in place (nn.ReLU's backward, newConvolution.py:150-159 under :184)
+__global__ __launch_bounds__(BLOCK) void relu_mask_inplace_kernel(float *__restrict__ gx,
+                                                                  const float *__restrict__ m,
+                                                                  long long n)
+{
+    for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < n;
+         i += (long long)gridDim.x * BLOCK)
+        gx[i] = m[i] > 0.0f ? gx[i] : 0.0f;
+}
+
+extern "C" int wm_relu_mask_f32(float *gx, const float *ymask, int64_t n, void *stream)
+{
+    WM_REQUIRE(gx && ymask && n >= 0, WM_ERR_INVALID, "wm_relu_mask_f32: bad arguments");
+    if (n == 0) return WM_OK;
+    WM_REQUIRE(wm_num_cus() > 0, WM_ERR_NO_DEVICE, "wm_relu_mask_f32: no HIP device");
+    hipLaunchKernelGGL(relu_mask_inplace_kernel, dim3(generic_grid(n)), dim3(BLOCK), 0,
+                       (hipStream_t)stream, gx, ymask, (long long)n);
+    WM_LAUNCH_CHECK("relu_mask_inplace_kernel");
+    return WM_OK;
+}
+
 extern "C" size_t wm_conv2d_bwd_wb_workspace_bytes(int N, int Cin, int H, int W, int Cout, int kH,
                                                    int kW)
 {

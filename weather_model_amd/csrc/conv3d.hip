@@ -807,7 +807,8 @@ template <int CT>
 __global__ __launch_bounds__(BLOCK) void conv3d_bwd_data_rows_kernel(const float *__restrict__ gy,
                                                                      const float *__restrict__ w,
                                                                      float *__restrict__ gx, Dims3 d,
-                                                                     int K2)
+                                                                     int K2,
+                                                                     const float *__restrict__ mask)
 {
     extern __shared__ __align__(16) float smem[];
     const int steps = rows_steps(K2);
@@ -870,6 +871,27 @@ __global__ __launch_bounds__(BLOCK) void conv3d_bwd_data_rows_kernel(const float
 
         char *xb = (char *)(gx + (size_t)b_ * gxsample);
         const unsigned sp0 = 4u * ((unsigned)((dz * d.H + h) * d.W + w0 + j) + (unsigned)(4 * g) * V);
+        if (mask) {
+            // ReLU backward of the layer BELOW fused into this store: mask is that layer's output
+            // (same shape as gx), and its input gradient is gx where the output was positive
+            const char *mb = (const char *)(mask + (size_t)b_ * gxsample);
+#pragma unroll
+            for (int t = 0; t < CT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ch = t * 16 + 4 * g + r;
+                    if (ch < d.Cin) {
+                        const unsigned xo = sp0 + 4u * (unsigned)(t * 16 + r) * V;
+                        float mv[CPW];
+#pragma unroll
+                        for (int c = 0; c < CPW; ++c) mv[c] = *(const float *)(mb + xo + 64u * c);
+#pragma unroll
+                        for (int c = 0; c < CPW; ++c)
+                            *(float *)(xb + xo + 64u * c) = mv[c] > 0.0f ? acc[c][t][r] : 0.0f;
+                    }
+                }
+            continue;
+        }
 #pragma unroll
         for (int t = 0; t < CT; ++t)
 #pragma unroll
@@ -882,6 +904,16 @@ __global__ __launch_bounds__(BLOCK) void conv3d_bwd_data_rows_kernel(const float
                 }
             }
     }
+}
+
+// gx = mask > 0 ? gx : 0 -- the ReLU backward for the kernels that do not fuse it
+__global__ __launch_bounds__(BLOCK) void relu_mask_kernel(float *__restrict__ gx,
+                                                          const float *__restrict__ mask,
+                                                          long long n)
+{
+    for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < n;
+         i += (long long)gridDim.x * BLOCK)
+        gx[i] = mask[i] > 0.0f ? gx[i] : 0.0f;
 }
 
 // ------------------------------------------------------------------------------ backward w, b
@@ -1737,9 +1769,43 @@ extern "C" int wm_conv3d_fwd_f32(const float *x, const float *w, const float *b,
     return WM_OK;
 }
 
+static int conv3d_bwd_data_impl(const float *gy, const float *w, float *gx, const float *mask,
+                                int B, int Cin, int D, int H, int W, int Cout, int kD, int kH,
+                                int kW, void *stream);
+
 extern "C" int wm_conv3d_bwd_data_f32(const float *gy, const float *w, float *gx, int B, int Cin,
                                       int D, int H, int W, int Cout, int kD, int kH, int kW,
                                       void *stream)
+{
+    return conv3d_bwd_data_impl(gy, w, gx, nullptr, B, Cin, D, H, W, Cout, kD, kH, kW, stream);
+}
+
+extern "C" int wm_conv3d_bwd_data_relu_f32(const float *gy, const float *w, const float *mask,
+                                           float *gx, int B, int Cin, int D, int H, int W, int Cout,
+                                           int kD, int kH, int kW, void *stream)
+{
+    WM_REQUIRE(mask, WM_ERR_INVALID, "wm_conv3d_bwd_data_relu_f32: null mask");
+    return conv3d_bwd_data_impl(gy, w, gx, mask, B, Cin, D, H, W, Cout, kD, kH, kW, stream);
+}
+
+// every path but the row kernel applies the mask in a second, element-wise launch
+#define WM_BWD_DATA_DONE(name)                                                                 \
+    do {                                                                                       \
+        WM_LAUNCH_CHECK(name);                                                                 \
+        if (mask) {                                                                            \
+            const long long n_ = (long long)B * Cin * D * H * W;                               \
+            long long g_ = (n_ + BLOCK - 1) / BLOCK;                                           \
+            if (g_ > (long long)wm_num_cus() * 16) g_ = (long long)wm_num_cus() * 16;          \
+            hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)g_), dim3(BLOCK), 0, st, gx,   \
+                               mask, n_);                                                      \
+            WM_LAUNCH_CHECK("relu_mask_kernel");                                               \
+        }                                                                                      \
+        return WM_OK;                                                                          \
+    } while (0)
+
+static int conv3d_bwd_data_impl(const float *gy, const float *w, float *gx, const float *mask,
+                                int B, int Cin, int D, int H, int W, int Cout, int kD, int kH,
+                                int kW, void *stream)
 {
     WM_REQUIRE(gy && w && gx, WM_ERR_INVALID, "wm_conv3d_bwd_data_f32: null pointer");
     Dims3 d;
@@ -1766,13 +1832,13 @@ extern "C" int wm_conv3d_bwd_data_f32(const float *gy, const float *w, float *gx
             if (grid > (units + WAVES - 1) / WAVES) grid = ((units + WAVES - 1) / WAVES + 7) & ~7;
             if (ctk == 1)
                 hipLaunchKernelGGL(conv3d_bwd_data_rows_kernel<1>, dim3(grid), dim3(BLOCK), lds, st,
-                                   gy, w, gx, d, K2);
+                                   gy, w, gx, d, K2, mask);
             else if (ctk == 2)
                 hipLaunchKernelGGL(conv3d_bwd_data_rows_kernel<2>, dim3(grid), dim3(BLOCK), lds, st,
-                                   gy, w, gx, d, K2);
+                                   gy, w, gx, d, K2, mask);
             else
                 hipLaunchKernelGGL(conv3d_bwd_data_rows_kernel<4>, dim3(grid), dim3(BLOCK), lds, st,
-                                   gy, w, gx, d, K2);
+                                   gy, w, gx, d, K2, mask);
             WM_LAUNCH_CHECK("conv3d_bwd_data_rows_kernel");
             return WM_OK;
         }
@@ -1785,8 +1851,7 @@ extern "C" int wm_conv3d_bwd_data_f32(const float *gy, const float *w, float *gx
         else
             hipLaunchKernelGGL(conv3d_bwd_data_wide_kernel<4>, dim3(wblocks), dim3(BLOCK), 0, st, gy,
                                w, gx, d, K2, Mtot);
-        WM_LAUNCH_CHECK("conv3d_bwd_data_wide_kernel");
-        return WM_OK;
+        WM_BWD_DATA_DONE("conv3d_bwd_data_wide_kernel");
     }
     const int blocks = (Mtot + 15) / 16;            // one workgroup per 16-position tile
     const bool deep = blocks <= 4 * wm_num_cus();
@@ -1808,8 +1873,7 @@ extern "C" int wm_conv3d_bwd_data_f32(const float *gy, const float *w, float *gx
     else if (ct == 2) { BWD_SPLITK(2); }
     else { BWD_SPLITK(4); }
 #undef BWD_SPLITK
-    WM_LAUNCH_CHECK("conv3d_bwd_data_kernel");
-    return WM_OK;
+    WM_BWD_DATA_DONE("conv3d_bwd_data_kernel");
 }
 
 extern "C" size_t wm_conv3d_bwd_wb_workspace_bytes(int B, int Cin, int D, int H, int W, int Cout,

@@ -44,11 +44,11 @@ def _conv_dims(x, w):
     return N, Cin, H, W, Cout, kH, kW
 
 
-def conv2d_forward(x, w, b=None, relu=False):
+def conv2d_forward(x, w, b=None, relu=False, out=None):
     x, w = _req(x, "input"), _req(w, "weight")
     b = None if b is None else _req(b, "bias")
     N, Cin, H, W, Cout, kH, kW = _conv_dims(x, w)
-    y = torch.empty((N, Cout, H - kH + 1, W - kW + 1), device=x.device, dtype=torch.float32)
+    y = _out_like(out, (N, Cout, H - kH + 1, W - kW + 1), x.device, "out")
     with torch.cuda.device(x.device):
         _lib.check(_lib.lib().wm_conv2d_fwd_f32(
             x.data_ptr(), w.data_ptr(), 0 if b is None else b.data_ptr(), y.data_ptr(),
@@ -56,27 +56,71 @@ def conv2d_forward(x, w, b=None, relu=False):
     return y
 
 
-def conv2d_backward_data(gy, w, x_shape):
+def _out_like(out, shape, device, name):
+    if out is None:
+        return torch.empty(shape, device=device, dtype=torch.float32)
+    if tuple(out.shape) != tuple(shape) or out.dtype != torch.float32 or not out.is_cuda or \
+            not out.is_contiguous() or out.device != device:
+        raise ValueError(f"{name} must be a contiguous float32 {tuple(shape)} tensor on {device}")
+    return out
+
+
+def conv2d_backward_data(gy, w, x_shape, relu_mask=None, out=None):
+    """grad_input of the conv; with ``relu_mask`` (the post-ReLU output of the layer below, shaped
+    like the result) the ReLU backward is fused in: gx = relu_mask > 0 ? gx : 0."""
     gy, w = _req(gy, "grad_output"), _req(w, "weight")
-    N, Cin, H, W = x_shape
-    Cout, _, kH, kW = w.shape
-    gx = torch.empty((N, Cin, H, W), device=gy.device, dtype=torch.float32)
+    N, Cin, H, W = (int(v) for v in x_shape)
+    Cout, Cin2, kH, kW = w.shape
+    if Cin2 != Cin or tuple(gy.shape) != (N, Cout, H - kH + 1, W - kW + 1):
+        raise ValueError(f"grad_output {tuple(gy.shape)} / weight {tuple(w.shape)} do not belong "
+                         f"to an input of shape {tuple(x_shape)}")
+    gx = _out_like(out, (N, Cin, H, W), gy.device, "out")
     with torch.cuda.device(gy.device):
-        _lib.check(_lib.lib().wm_conv2d_bwd_data_f32(
-            gy.data_ptr(), w.data_ptr(), gx.data_ptr(), N, Cin, H, W, Cout, kH, kW, _stream()))
+        if relu_mask is None:
+            _lib.check(_lib.lib().wm_conv2d_bwd_data_f32(
+                gy.data_ptr(), w.data_ptr(), gx.data_ptr(), N, Cin, H, W, Cout, kH, kW, _stream()))
+        else:
+            m = _req(relu_mask, "relu_mask")
+            if tuple(m.shape) != (N, Cin, H, W):
+                raise ValueError(f"relu_mask must be {(N, Cin, H, W)}, got {tuple(m.shape)}")
+            _lib.check(_lib.lib().wm_conv2d_bwd_data_relu_f32(
+                gy.data_ptr(), w.data_ptr(), m.data_ptr(), gx.data_ptr(), N, Cin, H, W, Cout, kH,
+                kW, _stream()))
     return gx
 
 
-def conv2d_backward_wb(x, gy, w_shape, need_bias=True):
+def relu_mask_(g, y):
+    """In place g = y > 0 ? g : 0 (the backward of the ReLU whose output is y)."""
+    g, y = _req(g, "grad"), _req(y, "output")
+    if g.shape != y.shape or not g.is_contiguous():
+        raise ValueError("grad and output must be contiguous tensors of one shape")
+    with torch.cuda.device(g.device):
+        _lib.check(_lib.lib().wm_relu_mask_f32(g.data_ptr(), y.data_ptr(), g.numel(), _stream()))
+    return g
+
+
+def conv2d_bwd_wb_workspace(x_shape, w_shape, device="cuda"):
+    """A workspace tensor for ``conv2d_backward_wb(..., ws=)`` (reusable across calls of one shape)."""
+    N, Cin, H, W = (int(v) for v in x_shape)
+    Cout, _, kH, kW = (int(v) for v in w_shape)
+    with torch.cuda.device(device):
+        nbytes = _lib.lib().wm_conv2d_bwd_wb_workspace_bytes(N, Cin, H, W, Cout, kH, kW)
+    return torch.empty((max(nbytes, 8),), device=device, dtype=torch.uint8)
+
+
+def conv2d_backward_wb(x, gy, w_shape, need_bias=True, ws=None, out_w=None, out_b=None):
     x, gy = _req(x, "input"), _req(gy, "grad_output")
     N, Cin, H, W = x.shape
     Cout, _, kH, kW = w_shape
     L = _lib.lib()
     with torch.cuda.device(x.device):
         nbytes = L.wm_conv2d_bwd_wb_workspace_bytes(N, Cin, H, W, Cout, kH, kW)
-        ws = torch.empty((max(nbytes, 8),), device=x.device, dtype=torch.uint8)
-        gw = torch.empty(tuple(w_shape), device=x.device, dtype=torch.float32)
-        gb = torch.empty((Cout,), device=x.device, dtype=torch.float32) if need_bias else None
+        if ws is None:
+            ws = torch.empty((max(nbytes, 8),), device=x.device, dtype=torch.uint8)
+        elif ws.numel() < nbytes or not ws.is_cuda or ws.dtype != torch.uint8:
+            raise ValueError(f"ws must be a CUDA uint8 tensor of at least {nbytes} bytes")
+        gw = _out_like(out_w, tuple(w_shape), x.device, "out_w")
+        gb = _out_like(out_b, (Cout,), x.device, "out_b") if need_bias else None
         _lib.check(L.wm_conv2d_bwd_wb_f32(
             x.data_ptr(), gy.data_ptr(), gw.data_ptr(), 0 if gb is None else gb.data_ptr(),
             ws.data_ptr(), ws.numel(), N, Cin, H, W, Cout, kH, kW, _stream()))
