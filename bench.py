@@ -638,6 +638,27 @@ def run_model(steps, warmup, rank, world, cpu_base, B=721 * 1440):
                         "executed_TFLOPs": EXEC_FLOPS_PER_SAMPLE * B / (kms * 1e-3) / 1e12,
                         "executed_frac_of_peak": EXEC_FLOPS_PER_SAMPLE * B / (kms * 1e-3) / 1e12
                         / MFMA_F32_PEAK_TF}}
+    # the same step fed from a resident (T,1,721,1440,6) volume by sample index: no gather launch,
+    # no x / y arrays (wm_model_train_gather_f32)
+    if B == 721 * 1440:
+        T = 9
+        vol = ops.synth_uniform((T, 1, 721, 1440, 6), seed=22, offset=rank * T * B * 6)
+        gev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        nrep = max(3, min(steps, 10))
+        for i in range(nrep + 2):
+            if i == 2:
+                gev[0].record()
+            _lib.check(L.wm_model_train_gather_f32(
+                params.data_ptr(), vol.data_ptr(), 0, 0, T, 1, 721, 1440, T - 6, 1, 721, 1440, 0, 3,
+                6, out.data_ptr(), loss.data_ptr(), grads.data_ptr(), ws.data_ptr(), ws.numel(), B,
+                B * world, torch.cuda.current_stream().cuda_stream))
+        gev[1].record()
+        torch.cuda.synchronize()
+        gms = gev[0].elapsed_time(gev[1]) / nrep
+        res["gather_fed"] = {"train_ms": gms, "value_per_gpu": B / (gms * 1e-3),
+                             "note": "forward + backward of the same batch read from the volume by "
+                                     "index (replaces wm_gather_triplets_f32 + wm_model_train_f32)"}
+        del vol
     if cpu_base and rank == 0 and world == 1:
         pd, off = {}, 0
         pc = params.cpu().numpy()

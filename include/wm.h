@@ -183,6 +183,17 @@ int    wm_model_train_f32(const float *params, const float *x, const float *y, c
                           float *out, float *loss, float *grads, void *workspace,
                           size_t workspace_bytes, int64_t B, int64_t B_global, void *stream);
 
+/* wm_model_train_f32 (fused MSE form) fed straight from the resident volume: sample b is the one
+ * wm_gather_triplets_f32 would have produced for index idx[b] (or idx0 + b when idx is NULL) --
+ * CustomDataset.__getitem__, newConvolution.py:86-106, followed by model(x), loss_fn, backward
+ * (:180-184) -- without writing x (B,2,6) and y (B,6) first (144 B per sample each way).  vol is
+ * (T,Z,Y,X,6); the other arguments are those of the two calls it replaces. */
+int    wm_model_train_gather_f32(const float *params, const float *vol, const int64_t *idx,
+                                 int64_t idx0, int T, int Z, int Y, int X, int St, int Sz, int Sy,
+                                 int Sx, int time_offset, int d_mid, int d_end, float *out,
+                                 float *loss, float *grads, void *workspace,
+                                 size_t workspace_bytes, int64_t B, int64_t B_global, void *stream);
+
 /* torch.optim.Adam step with the reference's defaults semantics (newConvolution.py:185,225):
  * no weight decay, no amsgrad; step counts from 1; grads are multiplied by grad_scale first.
  * lr, betas and eps are doubles, as torch holds them: the bias corrections 1 - beta^step and the

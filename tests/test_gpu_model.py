@@ -243,3 +243,25 @@ def test_device_trainer_matches_module_training():
     l1 = trainer.epoch(ds, batch_size=64, shuffle=True, seed=1)
     l2 = trainer.epoch(ds, batch_size=64, shuffle=True, seed=2)
     assert l2 < l0
+
+
+def test_model_train_gather_equals_gather_then_train():
+    """wm_model_train_gather_f32 (samples read from the resident volume by index) is bit for bit
+    wm_gather_triplets_f32 followed by wm_model_train_f32: outputs, loss and all 20566 gradients,
+    for an index list (with repeats and wrap-around) and for a contiguous range."""
+    from weather_model_amd import ops, synth
+    rng = {n: synth.uniform(700 + k, shp, -0.3, 0.3) for k, (n, shp) in enumerate(ops.MODEL_PARAM_SHAPES)}
+    p = torch.from_numpy(_flat(rng)).cuda()
+    T, Z, Y, X = 11, 3, 17, 29
+    vol = ops.synth_uniform((T, Z, Y, X, 6), seed=710)
+    shape = (T - 7, Z - 1, Y - 2, X - 5)
+    n = int(np.prod(shape))
+    gen = torch.Generator().manual_seed(3)
+    idx = torch.randint(-5, 2 * n, (1003,), generator=gen).cuda()
+    for kw in ({"indices": idx}, {"first": 37, "count": 2 * n + 11}):
+        x, y = ops.gather_triplets(vol, shape, time_offset=1, **kw)
+        o0, l0, g0 = ops.model_train(p, x, y=y)
+        o1, l1, g1 = ops.model_train_gather(p, vol, shape, time_offset=1, **kw)
+        assert torch.equal(o0, o1) and torch.equal(g0, g1) and float(l0) == float(l1)
+    with pytest.raises(Exception, match="leaves"):
+        ops.model_train_gather(p, vol, (T - 5, Z, Y, X), count=8)

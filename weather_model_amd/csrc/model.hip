@@ -265,13 +265,44 @@ extern "C" int wm_debug_read_stamps(unsigned long long *dst)
 #define STAMP(k)
 #endif
 
+// Where a GATHER launch takes its samples from: the resident (T,Z,Y,X,6) volume and the index
+// decode of CustomDataset.__getitem__ (newConvolution.py:93-106), i.e. what wm_gather_triplets_f32
+// would have written to x and y first (144 B per sample each way).
+struct ModelGather {
+    const float *vol;
+    const long long *idx;
+    long long idx0;
+    unsigned long long plane;                 // elements of one time slice = Z*Y*X*6
+    unsigned tot, Sx, Sy, Sz, St, Y, X, time_offset, d_mid, d_end;
+};
+
+// element offset in vol of variable 0 of sample `smp` at its start time
+__device__ __forceinline__ size_t gather_base(const ModelGather &gs, long long smp)
+{
+    unsigned id;
+    if (gs.idx) {
+        long long raw = gs.idx[smp] % (long long)gs.tot;
+        if (raw < 0) raw += gs.tot;
+        id = (unsigned)raw;
+    } else {
+        id = (unsigned)((unsigned long long)(gs.idx0 + smp) % gs.tot);
+    }
+    const unsigned q1 = id / gs.Sx, column = id - q1 * gs.Sx;
+    const unsigned q2 = q1 / gs.Sy, row = q1 - q2 * gs.Sy;
+    const unsigned q3 = q2 / gs.Sz, height = q2 - q3 * gs.Sz;
+    const unsigned time = q3 % gs.St + gs.time_offset;
+    return (size_t)time * gs.plane + ((size_t)(height * gs.Y + row) * gs.X + column) * 6;
+}
+
 // MODE 0: forward only.  MODE 1: forward + backward with dL/dout = 2 (out - y) * dscale (fused
-// MSE).  MODE 2: forward + backward with dL/dout given.
-template <int MODE>
+// MSE).  MODE 2: forward + backward with dL/dout given.  GATHER (MODE 1): x and y are read from
+// the volume by sample index instead of from (B,2,6) / (B,6) arrays.
+template <int MODE, bool GATHER = false>
 __global__ __launch_bounds__(THREADS) void model_kernel(
     const float *__restrict__ prm, const float *__restrict__ x, const float *__restrict__ y,
     const float *__restrict__ dout, float *__restrict__ out, float *__restrict__ gtiles,
-    float *__restrict__ loss_part, long long B, float dscale, const float *__restrict__ l1pack)
+    float *__restrict__ loss_part, long long B, float dscale, const float *__restrict__ l1pack,
+    ModelGather gs)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -350,10 +381,14 @@ __global__ __launch_bounds__(THREADS) void model_kernel(
     // (1.8 k cycles of HBM latency per tile, measured with cycle stamps)
     float xnext = 0.0f;
     bool xvalid = false;
+    // GATHER: row xr of x is the slice d_end * xr after the sample's start time, variable xcol >> 4
+    const size_t xgoff = GATHER ? (size_t)xr * gs.d_end * gs.plane + (size_t)(xcol >> 4) : 0;
     if (tid < 2 * NC && (long long)blockIdx.x < ntiles) {
         const long long smp = (long long)blockIdx.x * TS + xs;
         xvalid = smp < B;
-        xnext = x[(smp < B ? smp : B - 1) * 12 + xoff];
+        const long long sc = smp < B ? smp : B - 1;
+        if constexpr (GATHER) xnext = gs.vol[gather_base(gs, sc) + xgoff];
+        else xnext = x[sc * 12 + xoff];
     }
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long long s0 = tile * TS;
@@ -365,7 +400,9 @@ __global__ __launch_bounds__(THREADS) void model_kernel(
             lds[L_EE + (1 + xr) * NP + xcol] = xv;
             const long long smp = (tile + gridDim.x) * TS + xs;
             xvalid = tile + gridDim.x < ntiles && smp < B;
-            xnext = x[(smp < B ? smp : B - 1) * 12 + xoff];
+            const long long sc = smp < B ? smp : B - 1;
+            if constexpr (GATHER) xnext = gs.vol[gather_base(gs, sc) + xgoff];
+            else xnext = x[sc * 12 + xoff];
         }
         if constexpr (MODE != 0) {
             // opaque per-tile copy of the lane offset: otherwise the loads are loop-invariant and
@@ -382,10 +419,13 @@ __global__ __launch_bounds__(THREADS) void model_kernel(
         if constexpr (MODE != 0) {
             if (wave == 0) {
                 const long long smp = s0 + i < B ? s0 + i : B - 1;
+                size_t ybase = 0;
+                if constexpr (GATHER) ybase = gather_base(gs, smp) + (size_t)gs.d_mid * gs.plane;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int m = 4 * g + r < 6 ? 4 * g + r : 5;
-                    tgt[r] = MODE == 1 ? y[smp * 6 + m] : dout[smp * 6 + m];
+                    if constexpr (GATHER) tgt[r] = gs.vol[ybase + m];
+                    else tgt[r] = MODE == 1 ? y[smp * 6 + m] : dout[smp * 6 + m];
                 }
             }
         }
@@ -720,28 +760,28 @@ __global__ __launch_bounds__(256) void model_pack_l1_kernel(const float *__restr
     l1pack[e] = v;
 }
 
-template <int MODE>
+template <int MODE, bool GATHER = false>
 int model_launch(const float *prm, const float *x, const float *y, const float *dout, float *out,
                  float *gtiles, float *loss_part, long long B, float dscale, int grid,
-                 hipStream_t st, float *l1pack = nullptr)
+                 hipStream_t st, float *l1pack = nullptr, ModelGather gs = ModelGather())
 {
     // per device: the attribute belongs to the function's image on the current device
-    static bool attr_set_dev[64][3] = {};
+    static bool attr_set_dev[64][4] = {};
     int dev = 0;
     WM_HIP(hipGetDevice(&dev));
-    bool (&attr_set)[3] = attr_set_dev[dev & 63];
-    if (!attr_set[MODE]) {
-        WM_HIP(hipFuncSetAttribute((const void *)model_kernel<MODE>,
+    bool (&attr_set)[4] = attr_set_dev[dev & 63];
+    if (!attr_set[GATHER ? 3 : MODE]) {
+        WM_HIP(hipFuncSetAttribute((const void *)model_kernel<MODE, GATHER>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-        attr_set[MODE] = true;
+        attr_set[GATHER ? 3 : MODE] = true;
     }
     if (MODE != 0) {
         hipLaunchKernelGGL(model_pack_l1_kernel, dim3((unsigned)((L1PACK_FLOATS + 255) / 256)),
                            dim3(256), 0, st, prm, l1pack);
         WM_LAUNCH_CHECK("model_pack_l1_kernel");
     }
-    hipLaunchKernelGGL((model_kernel<MODE>), dim3(grid), dim3(THREADS), LDS_BYTES, st, prm, x, y,
-                       dout, out, gtiles, loss_part, B, dscale, (const float *)l1pack);
+    hipLaunchKernelGGL((model_kernel<MODE, GATHER>), dim3(grid), dim3(THREADS), LDS_BYTES, st, prm,
+                       x, y, dout, out, gtiles, loss_part, B, dscale, (const float *)l1pack, gs);
     WM_LAUNCH_CHECK("model_kernel");
     return WM_OK;
 }
@@ -769,6 +809,11 @@ extern "C" int wm_model_fwd_f32(const float *params, const float *x, float *out,
                            model_grid(B), (hipStream_t)stream);
 }
 
+static int model_train_impl(const float *params, const float *x, const float *y, const float *dout,
+                            const ModelGather *gs, float *out, float *loss, float *grads,
+                            void *workspace, size_t workspace_bytes, int64_t B, int64_t B_global,
+                            void *stream);
+
 extern "C" int wm_model_train_f32(const float *params, const float *x, const float *y,
                                   const float *dout, float *out, float *loss, float *grads,
                                   void *workspace, size_t workspace_bytes, int64_t B,
@@ -777,6 +822,46 @@ extern "C" int wm_model_train_f32(const float *params, const float *x, const flo
     WM_REQUIRE(params && x && out && grads, WM_ERR_INVALID, "wm_model_train_f32: null pointer");
     WM_REQUIRE((y != nullptr) != (dout != nullptr), WM_ERR_INVALID,
                "wm_model_train_f32: pass exactly one of y (fused MSE) and dout (given gradient)");
+    return model_train_impl(params, x, y, dout, nullptr, out, loss, grads, workspace,
+                            workspace_bytes, B, B_global, stream);
+}
+
+extern "C" int wm_model_train_gather_f32(const float *params, const float *vol, const int64_t *idx,
+                                         int64_t idx0, int T, int Z, int Y, int X, int St, int Sz,
+                                         int Sy, int Sx, int time_offset, int d_mid, int d_end,
+                                         float *out, float *loss, float *grads, void *workspace,
+                                         size_t workspace_bytes, int64_t B, int64_t B_global,
+                                         void *stream)
+{
+    WM_REQUIRE(params && vol && out && grads, WM_ERR_INVALID,
+               "wm_model_train_gather_f32: null pointer");
+    WM_REQUIRE(T > 0 && Z > 0 && Y > 0 && X > 0 && St > 0 && Sz > 0 && Sy > 0 && Sx > 0 &&
+                   Sz <= Z && Sy <= Y && Sx <= X,
+               WM_ERR_INVALID, "wm_model_train_gather_f32: sample shape outside the volume");
+    WM_REQUIRE(time_offset >= 0 && d_mid >= 0 && d_end >= 0 &&
+                   time_offset + St - 1 + (d_end > d_mid ? d_end : d_mid) < T,
+               WM_ERR_INVALID, "wm_model_train_gather_f32: time %d + %d steps + offset %d leaves "
+               "the %d slices", time_offset, St, d_end > d_mid ? d_end : d_mid, T);
+    const long long tot = (long long)St * Sz * Sy * Sx;
+    WM_REQUIRE(tot < (1ll << 32) && (idx || idx0 >= 0), WM_ERR_UNSUPPORTED,
+               "wm_model_train_gather_f32: sample shape of 2^32 entries or more, or negative index");
+    ModelGather gs;
+    gs.vol = vol;
+    gs.idx = (const long long *)idx;
+    gs.idx0 = idx0;
+    gs.plane = (unsigned long long)Z * Y * X * 6;
+    gs.tot = (unsigned)tot;
+    gs.Sx = Sx; gs.Sy = Sy; gs.Sz = Sz; gs.St = St; gs.Y = Y; gs.X = X;
+    gs.time_offset = time_offset; gs.d_mid = d_mid; gs.d_end = d_end;
+    return model_train_impl(params, nullptr, nullptr, nullptr, &gs, out, loss, grads, workspace,
+                            workspace_bytes, B, B_global, stream);
+}
+
+static int model_train_impl(const float *params, const float *x, const float *y, const float *dout,
+                            const ModelGather *gsp, float *out, float *loss, float *grads,
+                            void *workspace, size_t workspace_bytes, int64_t B, int64_t B_global,
+                            void *stream)
+{
     WM_REQUIRE(B > 0 && B_global >= B, WM_ERR_INVALID, "wm_model_train_f32: bad batch sizes");
     WM_REQUIRE(wm_num_cus() > 0, WM_ERR_NO_DEVICE, "wm_model_train_f32: no HIP device");
     const size_t need = wm_model_workspace_bytes(B);
@@ -790,7 +875,10 @@ extern "C" int wm_model_train_f32(const float *params, const float *x, const flo
     const float dscale = 1.0f / (6.0f * (float)B_global);
     int rc;
     float *l1pack = (float *)((char *)workspace + need - L1PACK_FLOATS * sizeof(float));
-    if (y) rc = model_launch<1>(params, x, y, nullptr, out, gtiles, loss_part, B, dscale, grid, st, l1pack);
+    if (gsp)
+        rc = model_launch<1, true>(params, nullptr, nullptr, nullptr, out, gtiles, loss_part, B,
+                                   dscale, grid, st, l1pack, *gsp);
+    else if (y) rc = model_launch<1>(params, x, y, nullptr, out, gtiles, loss_part, B, dscale, grid, st, l1pack);
     else   rc = model_launch<2>(params, x, nullptr, dout, out, gtiles, loss_part, B, dscale, grid, st, l1pack);
     if (rc) return rc;
     double *tsum = (double *)((char *)l1pack - (size_t)GSPLIT * NTILES * 256 * sizeof(double));
@@ -798,8 +886,8 @@ extern "C" int wm_model_train_f32(const float *params, const float *x, const flo
                        tsum);
     WM_LAUNCH_CHECK("model_tile_reduce_kernel");
     hipLaunchKernelGGL(model_grad_finalize_kernel, dim3((NPARAM + 255) / 256), dim3(256), 0, st,
-                       tsum, y ? loss_part : (const float *)nullptr, grid, grads,
-                       y ? loss : (float *)nullptr, dscale);
+                       tsum, (y || gsp) ? loss_part : (const float *)nullptr, grid, grads,
+                       (y || gsp) ? loss : (float *)nullptr, dscale);
     WM_LAUNCH_CHECK("model_grad_finalize_kernel");
     return WM_OK;
 }

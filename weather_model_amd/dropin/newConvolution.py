@@ -112,13 +112,18 @@ class CustomDataset(Dataset):
         y = self.gather_data(time + 3, height, row, column)
         return torch.stack((start_x, end_x), dim=0), y
 
-    def batch(self, indices, device=None):
-        """Many items at once: x (B,2,6), y (B,6).  The volume is laid out (T,Z,Y,X,6) once; on
-        the GPU the decode + triplet gather is one ``wm_gather_triplets_f32`` launch."""
+    def device_volume(self, device=None):
+        """The (T,Z,Y,X,6) layout of ``data`` on ``device``, built once."""
         want = None if device is None else torch.device(device)
         if self._vol is None or (want is not None and self._vol.device.type != want.type):
             vol = torch.stack([self.data[var][:, 0] for var in data_vars], dim=-1).float()
             self._vol = (vol.to(want) if want is not None else vol).contiguous()
+        return self._vol
+
+    def batch(self, indices, device=None):
+        """Many items at once: x (B,2,6), y (B,6).  The volume is laid out (T,Z,Y,X,6) once; on
+        the GPU the decode + triplet gather is one ``wm_gather_triplets_f32`` launch."""
+        self.device_volume(device)
         idx = torch.as_tensor(indices, device=self._vol.device, dtype=torch.long)
         if self._vol.is_cuda:
             return ops.gather_triplets(self._vol, self.shape, indices=idx,
@@ -276,8 +281,16 @@ class DeviceTrainer:
             # loss share.  Skipping it would pair this rank's NEXT collective with the others'
             # current one.
             if mine.numel() > 0:
-                x, y = dataset.batch(mine, device=dev)
-                _, loss, grads = ops.model_train(self.flat, x, y, batch_global=int(idx.numel()))
+                vol = dataset.device_volume(dev) if dev.type == "cuda" else None
+                if vol is not None:
+                    # one launch: the training kernel reads its samples from the volume by index
+                    _, loss, grads = ops.model_train_gather(
+                        self.flat, vol, dataset.shape, indices=mine,
+                        time_offset=dataset.time_offset, batch_global=int(idx.numel()))
+                else:
+                    x, y = dataset.batch(mine, device=dev)
+                    _, loss, grads = ops.model_train(self.flat, x, y,
+                                                     batch_global=int(idx.numel()))
                 total += loss
             else:
                 grads = torch.zeros_like(self.flat)

@@ -629,6 +629,42 @@ def model_train(flat_params, x, y=None, dout=None, batch_global=None, ws=None):
     return out, loss, grads
 
 
+def model_train_gather(flat_params, vol, shape, indices=None, first=0, count=None, time_offset=0,
+                       d_mid=3, d_end=6, batch_global=None, ws=None):
+    """``model_train(flat_params, *gather_triplets(vol, shape, ...))`` in one launch: the kernel
+    reads its samples from the resident (T,Z,Y,X,6) volume by index (wm_model_train_gather_f32).
+    Returns (out, loss, grads)."""
+    p = _req(flat_params, "params")
+    if p.numel() != MODEL_PARAM_COUNT:
+        raise ValueError(f"params must hold {MODEL_PARAM_COUNT} floats, got {p.numel()}")
+    vol = _req(vol, "volume")
+    if vol.dim() != 5 or vol.shape[4] != 6:
+        raise ValueError(f"volume must be (T,Z,Y,X,6), got {tuple(vol.shape)}")
+    T, Z, Y, X, _ = vol.shape
+    St, Sz, Sy, Sx = (int(v) for v in shape)
+    if indices is not None:
+        indices = _req(indices, "indices", torch.int64).reshape(-1)
+        B = indices.numel()
+    else:
+        B = int(count)
+    if B <= 0:
+        raise ValueError("model_train_gather needs at least one sample")
+    dev = vol.device
+    out = torch.empty((B, 6), device=dev, dtype=torch.float32)
+    grads = torch.empty((MODEL_PARAM_COUNT,), device=dev, dtype=torch.float32)
+    loss = torch.zeros((), device=dev, dtype=torch.float32)
+    L = _lib.lib()
+    with torch.cuda.device(dev):
+        if ws is None:
+            ws = torch.empty((L.wm_model_workspace_bytes(B),), device=dev, dtype=torch.uint8)
+        _lib.check(L.wm_model_train_gather_f32(
+            p.data_ptr(), vol.data_ptr(), 0 if indices is None else indices.data_ptr(), int(first),
+            T, Z, Y, X, St, Sz, Sy, Sx, int(time_offset), int(d_mid), int(d_end), out.data_ptr(),
+            loss.data_ptr(), grads.data_ptr(), ws.data_ptr(), ws.numel(), B,
+            int(batch_global or B), _stream()))
+    return out, loss, grads
+
+
 def adam_step(params, grads, m, v, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
     """In-place torch.optim.Adam step on flat float32 buffers (newConvolution.py:185,225)."""
     for name, t in (("params", params), ("grads", grads), ("m", m), ("v", v)):
