@@ -63,11 +63,13 @@ int wm_conv2d_bwd_data_f32(const float *gy, const float *w, float *gx,
 
 /* The same with the backward of the nn.ReLU that FOLLOWS the layer below (newConvolution.py:150,153,
  * 156,159 under loss.backward(), :184) fused in: ymask is that layer's post-ReLU output, shaped like
- * gx, and gx = ymask > 0 ? gx : 0.  wm_relu_mask_f32 is the stand-alone form (in place). */
+ * gx, and gx = ymask > 0 ? gx : 0.  wm_relu_mask_f32 is the stand-alone form (in place),
+ * wm_relu_mask_to_f32 writes out = ymask > 0 ? g : 0 to a separate buffer. */
 int wm_conv2d_bwd_data_relu_f32(const float *gy, const float *w, const float *ymask, float *gx,
                                 int N, int Cin, int H, int W, int Cout, int kH, int kW,
                                 void *stream);
 int wm_relu_mask_f32(float *gx, const float *ymask, int64_t n, void *stream);
+int wm_relu_mask_to_f32(const float *g, const float *ymask, float *out, int64_t n, void *stream);
 
 /* Replaces the grad_weight and grad_bias legs (newConvolution.py:184):
  *   gw[o,c,kh,kw] = sum_{n,i,j} gy[n,o,i,j] x[n,c,i+kh,j+kw],  gb[o] = sum_{n,i,j} gy[n,o,i,j].

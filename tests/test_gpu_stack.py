@@ -49,7 +49,7 @@ def test_stack_matches_float64_oracle(shape):
         assert 0.05 < clipped < 0.95, (l, clipped)        # the mask is really exercised
         assert relinf(st.h[l].cpu().numpy(), h[l]) < TOL
     assert out is st.h[L]
-    flat = st.backward(dev(gout).clone())
+    flat = st.backward(dev(gout))
     for l in range(L):
         assert relinf(st.gw[l].cpu().numpy(), gws[l]) < TOL, l
         assert relinf(st.gb[l].cpu().numpy(), gbs[l]) < TOL, l
@@ -84,9 +84,9 @@ def test_stack_step_is_reproducible_and_reuses_buffers():
     bs = [ops.synth_uniform((C,), seed=320 + l, lo=-0.1, hi=0.1) for l in range(L)]
     g = ops.synth_uniform((N, C, H - 6, W - 6), seed=330, lo=-1.0, hi=1.0)
     st = ConvStack(ws, bs, x.shape)
-    a = st.step_grads(x, g.clone()).clone()
+    a = st.step_grads(x, g).clone()
     ptrs = [t.data_ptr() for t in st.h[1:]] + [st.flat_grads.data_ptr()]
-    b = st.step_grads(x, g.clone())
+    b = st.step_grads(x, g)
     assert torch.equal(a, b)
     assert ptrs == [t.data_ptr() for t in st.h[1:]] + [st.flat_grads.data_ptr()]
     assert st.flat_grads.numel() == L * (C * C * 9 + C)

@@ -19,6 +19,7 @@ SIGNATURES = {
     "wm_conv2d_bwd_data_f32": (c_int, [vp, vp, vp] + [c_int] * 7 + [vp]),
     "wm_conv2d_bwd_data_relu_f32": (c_int, [vp, vp, vp, vp] + [c_int] * 7 + [vp]),
     "wm_relu_mask_f32": (c_int, [vp, vp, c_i64, vp]),
+    "wm_relu_mask_to_f32": (c_int, [vp, vp, vp, c_i64, vp]),
     "wm_conv3d_bwd_data_relu_f32": (c_int, [vp, vp, vp, vp] + [c_int] * 9 + [vp]),
     "wm_conv2d_bwd_wb_workspace_bytes": (c_sz, [c_int] * 7),
     "wm_conv2d_bwd_wb_f32": (c_int, [vp, vp, vp, vp, vp, c_sz] + [c_int] * 7 + [vp]),

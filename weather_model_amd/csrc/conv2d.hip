@@ -1246,25 +1246,55 @@ extern "C" int wm_conv2d_bwd_data_relu_f32(const float *gy, const float *w, cons
     return wm_relu_mask_f32(gx, ymask, (int64_t)N * Cin * H * W, stream);
 }
 
-// gx = ymask > 0 ? gx : 0 in place (nn.ReLU's backward, newConvolution.py:150-159 under :184)
-__global__ __launch_bounds__(BLOCK) void relu_mask_inplace_kernel(float *__restrict__ gx,
-                                                                  const float *__restrict__ m,
-                                                                  long long n)
+// out = ymask > 0 ? g : 0 (nn.ReLU's backward, newConvolution.py:150-159 under :184); out may be g.
+// 16 bytes per lane when all three pointers allow it.
+__global__ __launch_bounds__(BLOCK) void relu_mask_kernel(const float *g, const float *__restrict__ m,
+                                                          float *out, long long n, int vec)
 {
-    for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < n;
-         i += (long long)gridDim.x * BLOCK)
-        gx[i] = m[i] > 0.0f ? gx[i] : 0.0f;
+    const long long stride = (long long)gridDim.x * BLOCK;
+    long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (vec) {
+        const long long n4 = n / 4;
+        for (; i < n4; i += stride) {
+            const f32x4 gv = reinterpret_cast<const f32x4 *>(g)[i];
+            const f32x4 mv = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(m) + i);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = mv[e] > 0.0f ? gv[e] : 0.0f;
+            reinterpret_cast<f32x4 *>(out)[i] = o;
+        }
+        i = n4 * 4 + (long long)blockIdx.x * BLOCK + threadIdx.x;
+        if (blockIdx.x != 0) return;
+    }
+    for (; i < n; i += stride) out[i] = m[i] > 0.0f ? g[i] : 0.0f;
+}
+
+static int relu_mask_launch(const float *g, const float *ymask, float *out, int64_t n, void *stream)
+{
+    if (n == 0) return WM_OK;
+    WM_REQUIRE(wm_num_cus() > 0, WM_ERR_NO_DEVICE, "wm_relu_mask_f32: no HIP device");
+    const int vec = ((((uintptr_t)g | (uintptr_t)ymask | (uintptr_t)out) & 15) == 0) ? 1 : 0;
+    long long grid = ((vec ? n / 4 : n) + BLOCK - 1) / BLOCK;
+    const long long cap = (long long)wm_num_cus() * 4;
+    if (grid > cap) grid = cap;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)grid), dim3(BLOCK), 0, (hipStream_t)stream,
+                       g, ymask, out, (long long)n, vec);
+    WM_LAUNCH_CHECK("relu_mask_kernel");
+    return WM_OK;
 }
 
 extern "C" int wm_relu_mask_f32(float *gx, const float *ymask, int64_t n, void *stream)
 {
     WM_REQUIRE(gx && ymask && n >= 0, WM_ERR_INVALID, "wm_relu_mask_f32: bad arguments");
-    if (n == 0) return WM_OK;
-    WM_REQUIRE(wm_num_cus() > 0, WM_ERR_NO_DEVICE, "wm_relu_mask_f32: no HIP device");
-    hipLaunchKernelGGL(relu_mask_inplace_kernel, dim3(generic_grid(n)), dim3(BLOCK), 0,
-                       (hipStream_t)stream, gx, ymask, (long long)n);
-    WM_LAUNCH_CHECK("relu_mask_inplace_kernel");
-    return WM_OK;
+    return relu_mask_launch(gx, ymask, gx, n, stream);
+}
+
+extern "C" int wm_relu_mask_to_f32(const float *g, const float *ymask, float *out, int64_t n,
+                                   void *stream)
+{
+    WM_REQUIRE(g && ymask && out && n >= 0, WM_ERR_INVALID, "wm_relu_mask_to_f32: bad arguments");
+    return relu_mask_launch(g, ymask, out, n, stream);
 }
 
 extern "C" size_t wm_conv2d_bwd_wb_workspace_bytes(int N, int Cin, int H, int W, int Cout, int kH,

@@ -99,6 +99,18 @@ def relu_mask_(g, y):
     return g
 
 
+def relu_mask(g, y, out=None):
+    """out = y > 0 ? g : 0 into a separate (or new) buffer."""
+    g, y = _req(g, "grad"), _req(y, "output")
+    if g.shape != y.shape:
+        raise ValueError("grad and output must have one shape")
+    o = _out_like(out, tuple(g.shape), g.device, "out")
+    with torch.cuda.device(g.device):
+        _lib.check(_lib.lib().wm_relu_mask_to_f32(g.data_ptr(), y.data_ptr(), o.data_ptr(),
+                                                  g.numel(), _stream()))
+    return o
+
+
 def conv2d_bwd_wb_workspace(x_shape, w_shape, device="cuda"):
     """A workspace tensor for ``conv2d_backward_wb(..., ws=)`` (reusable across calls of one shape)."""
     N, Cin, H, W = (int(v) for v in x_shape)

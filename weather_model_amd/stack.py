@@ -38,7 +38,7 @@ class ConvStack:
         L = len(self.w)
         self.h = [None] + [torch.empty(s, device=dev) for s in self.shapes[1:]]
         # gradient w.r.t. h_l for l = 1..L-1 (h_L's comes from the caller, h_0 needs none)
-        self.g = [None] + [torch.empty(s, device=dev) for s in self.shapes[1:L]] + [None]
+        self.g = [None] + [torch.empty(s, device=dev) for s in self.shapes[1:]]
         sizes = [w.numel() for w in self.w] + [b.numel() for b in self.b]
         self.flat_grads = torch.zeros((sum(sizes),), device=dev)
         views, off = [], 0
@@ -58,12 +58,13 @@ class ConvStack:
         return self.h[-1]
 
     def backward(self, gout, premasked=False):
-        """Gradients of every layer from dL/dh_L = ``gout`` (masked in place by h_L > 0 unless
-        ``premasked``).  Returns the flat gradient buffer [dW_1..dW_L, db_1..db_L]."""
+        """Gradients of every layer from dL/dh_L = ``gout`` (left untouched: its product with the
+        mask h_L > 0 goes to the stack's own buffer unless ``premasked``).  Returns the flat
+        gradient buffer [dW_1..dW_L, db_1..db_L]."""
         L = len(self.w)
         g = ops._req(gout, "grad_output")
         if not premasked:
-            ops.relu_mask_(g, self.h[L])
+            g = ops.relu_mask(g, self.h[L], out=self.g[L])
         for l in range(L, 0, -1):
             ops.conv2d_backward_wb(self.h[l - 1], g, self.w[l - 1].shape, ws=self.ws[l - 1],
                                    out_w=self.gw[l - 1], out_b=self.gb[l - 1])
