@@ -53,6 +53,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
 
+// 16-byte LDS (or global) accesses through a float pointer.  `*(f32x4 *)(array + i)` is NOT that:
+// clang takes the alignment of such an lvalue from the array's element type (4), and the backend
+// then splits the access into two ds_write2_b32 / ds_read2_b32.
+__device__ inline void wm_store4(float *p, f32x4 v) { *(f32x4 *)__builtin_assume_aligned(p, 16) = v; }
+__device__ inline f32x4 wm_load4(const float *p) { return *(const f32x4 *)__builtin_assume_aligned(p, 16); }
+
 __device__ __forceinline__ float wave_sum(float v)
 {
 #pragma unroll

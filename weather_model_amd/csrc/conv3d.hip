@@ -14,6 +14,8 @@
 // entries); the weight/bias gradient is split over n-chunks of 1024 outputs, written as float64
 // partials and combined in a fixed order (bitwise reproducible, no atomics).
 #include "common.h"
+#include <cstdlib>
+#include <mutex>
 
 namespace {
 
@@ -1133,6 +1135,13 @@ __host__ __device__ inline size_t wbr_lds_bytes(int cd, int kH, int ot)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src),    \
                                      (__attribute__((address_space(3))) void *)(dst), 16, 0, 0)
 
+#ifdef WM_WB_STAMPS
+// debug build only (tools/probe/wb_stamps.py): per workgroup, shader-clock cycles spent between
+// the two barriers of a unit (fill) and in the MFMA steps, and the wall/shader clocks at both ends
+__device__ unsigned long long wm_wb_stamps[1024 * 8 + 1024];
+#define WB_CLK() __builtin_readcyclecounter()
+#endif
+
 template <int OT, int KTW>
 __global__ __launch_bounds__(BLOCK) void conv3d_bwd_wb_rows_kernel(const float *__restrict__ x,
                                                                    const float *__restrict__ gy,
@@ -1215,6 +1224,10 @@ __global__ __launch_bounds__(BLOCK) void conv3d_bwd_wb_rows_kernel(const float *
     // workgroups per CU then, but no read-modify-write traffic: 32 -> 32 channels 3x3 1.87 ->
     // 1.77 ms), else in the slab
     constexpr bool REGSUM = wbr_regsum(OT, KTW);
+#ifdef WM_WB_STAMPS
+    unsigned long long t_fill = 0, t_comp = 0, t_flush = 0;
+    const unsigned long long c_begin = WB_CLK(), w_begin = wall_clock64();
+#endif
     double dsum[REGSUM ? KTW : 1][REGSUM ? OT : 1][4];
     if constexpr (REGSUM) {
 #pragma unroll
@@ -1255,6 +1268,9 @@ __global__ __launch_bounds__(BLOCK) void conv3d_bwd_wb_rows_kernel(const float *
         const int xs0 = min(ow0, d.W - WBR_XW), delta = ow0 - xs0;
         const float *xsrc = x + (size_t)b_ * xsample + (size_t)((od * d.H + oh) * d.W + xs0);
         const float *gsrc = gy + (size_t)b_ * gsample + (size_t)((od * d.OH + oh) * d.OW + ow0);
+#ifdef WM_WB_STAMPS
+        const unsigned long long c0 = WB_CLK();
+#endif
         __syncthreads();                                   // every wave is past its reads of the tile
         // input rows oh .. oh+kH-1: all of them at the top of a run or stripe, else the last
         for (int kh = (unit == ufirst || oh == 0) ? 0 : d.kH - 1; kh < d.kH; ++kh) {
@@ -1289,6 +1305,10 @@ __global__ __launch_bounds__(BLOCK) void conv3d_bwd_wb_rows_kernel(const float *
 #define WBR_MMA(a_, b_)                                                                      \
     _Pragma("unroll") for (int q = 0; q < KTW; ++q)                                          \
         _Pragma("unroll") for (int t = 0; t < OT; ++t) acc[q][t] = mma(a_[t], b_[q], acc[q][t]);
+#ifdef WM_WB_STAMPS
+        const unsigned long long c1 = WB_CLK();
+        t_fill += c1 - c0;
+#endif
         float a0[OT], b0[KTW], a1[OT], b1[KTW];
         int kofd[KTW];
 #pragma unroll
@@ -1311,7 +1331,13 @@ __global__ __launch_bounds__(BLOCK) void conv3d_bwd_wb_rows_kernel(const float *
         }
 #undef WBR_OPS
 #undef WBR_MMA
+#ifdef WM_WB_STAMPS
+        t_comp += WB_CLK() - c1;
+#endif
     }
+#ifdef WM_WB_STAMPS
+    const unsigned long long c2 = WB_CLK();
+#endif
     if constexpr (!REGSUM) {
     // WBR_FLUSH units (1024 outputs) of fp32 accumulation go to the float64 slab
 #pragma unroll
@@ -1339,7 +1365,18 @@ __global__ __launch_bounds__(BLOCK) void conv3d_bwd_wb_rows_kernel(const float *
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dsum[q][t][r] += (double)acc[q][t][r];
     }
+#ifdef WM_WB_STAMPS
+    t_flush += WB_CLK() - c2;
+#endif
     }
+#ifdef WM_WB_STAMPS
+    if ((tid & 63) == 0 && blockIdx.x < 1024 && wave < 1) {
+        unsigned long long *o = wm_wb_stamps + 8 * blockIdx.x;
+        o[0] = t_fill; o[1] = t_comp; o[2] = t_flush; o[3] = WB_CLK() - c_begin;
+        o[4] = wall_clock64() - w_begin; o[5] = w_begin; o[6] = uend - ufirst;
+        o[7] = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (8 << 6) | 4) /* HW_ID: cu id */;
+    }
+#endif
     if constexpr (REGSUM) {
 #pragma unroll
         for (int q = 0; q < KTW; ++q) {
@@ -1352,6 +1389,304 @@ __global__ __launch_bounds__(BLOCK) void conv3d_bwd_wb_rows_kernel(const float *
                     if (kin && t * 16 + 4 * g + r < d.Cout) *(double *)(sb + voff[q]) = dsum[q][t][r];
                 }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------ backward w, b, rows, staged
+// The row kernel above, re-cut after cycle stamps of its 32 -> 32 channels 3x3 run (tools/probe/
+// wb_stamps.py: shader clock 2.07 GHz under this load, 12.4 k clk per unit and workgroup, of which
+// 3.6 k between the two barriers, two workgroups per CU; 160 MFMAs x 32 clk = 5.1 k clk of issue
+// per unit and wave, a ninth of them on the bias tile and on an empty tile).  The time between
+// the barriers was not memory latency: while the other resident workgroup's wave streams MFMAs
+// on the same SIMD, every VALU instruction of this wave waits for an issue slot behind a 32-clk
+// MFMA, so the ~150 address and select instructions per unit cost as much as a third of the MFMAs.
+//  * the next unit's rows (one input row per (channel, kd) and the gy tile) are fetched into
+//    REGISTERS while this unit's MFMAs run (scalar base + 32-bit lane offset: no address
+//    arithmetic on the VALU) and written to LDS between the barriers (global_load ... lds cannot
+//    run ahead here: hipcc orders every later LDS read behind it with vmcnt(0));
+//  * the LDS address of every B operand for each of the kH phases of the row ring is computed
+//    once into an LDS table; a unit reads its KTW addresses back (LDS issue, not VALU);
+//  * taps >= K and channels >= Cout read whatever is there: a column or row of an MFMA product
+//    depends on nothing but its own operand, and those are never stored;
+//  * the bias gradient leaves the MFMA: its column of ones cost a whole tap tile (K + 1 = 289 ->
+//    19 tiles); the gy pieces are summed on their way from the stage registers into LDS;
+//  * the 4 waves can be split WOS ways over the channel tiles, the rest over the tap tiles
+//    (32 -> 32, 3x3: 2 x 2, nine tap tiles and one channel tile per wave: 9 MFMAs per step and
+//    no empty tile, where 1 x 4 ran 10 with two of 20 tiles idle).
+// Sums are float64 in registers (OTW * KTW <= 10), written once to the workgroup's slab.
+typedef float f32x4a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int WBS_NX = 3;          // staged 16-byte pieces per thread: an x row set, Cin*kD*17 <= 768
+constexpr int WBS_NG = 2;          // the gy tile, 32 channels x 16 pieces
+
+__host__ __device__ inline size_t wbs_lds_bytes(int cd, int kH, int ot, int ktw)
+{
+    return ((size_t)kH * wbr_slot_stride(cd) + (size_t)ot * 16 * WBR_GP + (size_t)kH * ktw * BLOCK) *
+           sizeof(float);
+}
+
+template <int OTW, int KTW, int WOS>
+__global__ __launch_bounds__(BLOCK) void conv3d_bwd_wb_staged_kernel(const float *__restrict__ x,
+                                                                     const float *__restrict__ gy,
+                                                                     double *__restrict__ partial,
+                                                                     Dims3 d, int K)
+{
+    constexpr int OT = OTW * WOS;
+    extern __shared__ __align__(16) float smem[];
+    const int CD = d.Cin * d.kD, SS = wbr_slot_stride(CD);
+    // [kH slots][CD][WBR_XP] x | [OT*16][WBR_GP] gy | [kH][KTW][BLOCK] B addresses
+    const int goff = d.kH * SS, toff = goff + OT * 16 * WBR_GP;
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int og = wave % WOS, tg = wave / WOS;            // channel-tile group, tap-tile group
+    const int S = d.OD * d.OH * d.OW;
+    double *slab = partial + (size_t)blockIdx.x * d.Cout * (K + 1);   // [Cout][K + 1], column K = bias
+
+    for (int e = tid; e < goff + OT * 16 * WBR_GP; e += BLOCK) smem[e] = 0.0f;
+    // B operand of tap tile q in phase p (= oh mod kH): tap k = (tg KTW + q) 16 + j =
+    // ((c kD + kd) kH + kh) kW + kw is at word ((kh + p) mod kH) SS + (c kD + kd) WBR_XP + kw + g
+    int *tab = (int *)smem + toff + tid;
+#pragma unroll
+    for (int q = 0; q < KTW; ++q) {
+        int k = (tg * KTW + q) * 16 + j;
+        if (k >= K) k = 0;
+        const int kw = k % d.kW, r_ = k / d.kW, kh = r_ % d.kH;
+        const int w_ = (r_ / d.kH) * WBR_XP + kw + g;
+        for (int p_ = 0; p_ < d.kH; ++p_) tab[(p_ * KTW + q) * BLOCK] = ((kh + p_) % d.kH) * SS + w_;
+    }
+    const int abase = goff + (og * OTW * 16 + j) * WBR_GP + g;
+
+    // staged pieces of this thread: x piece P = tid + 256 i is row P / 17, columns 4 (P % 17)..;
+    // gy piece is channel P / 16, columns 4 (tid % 16)..  A piece past the end goes to the pad
+    // columns of a row (never read) and loads from offset 0.
+    unsigned xsrc[WBS_NX], gsrc[WBS_NG];
+    int xdst[WBS_NX], gdst[WBS_NG];
+#pragma unroll
+    for (int i = 0; i < WBS_NX; ++i) {
+        const int P = tid + BLOCK * i, r_ = P / 17, pc = P - 17 * r_;
+        xsrc[i] = 0;
+        xdst[i] = (tid % CD) * WBR_XP + WBR_XW;
+        if (r_ < CD) {
+            xsrc[i] = 4u * (unsigned)(((r_ / d.kD) * d.D + r_ % d.kD) * d.H * d.W + 4 * pc);
+            xdst[i] = r_ * WBR_XP + 4 * pc;
+        }
+    }
+    bool gval[WBS_NG];
+#pragma unroll
+    for (int i = 0; i < WBS_NG; ++i) {
+        const int o = (tid + BLOCK * i) >> 4;
+        gval[i] = o < d.Cout;
+        gsrc[i] = gval[i] ? 4u * (unsigned)(o * S + 4 * (tid & 15)) : 0u;
+        gdst[i] = goff + (gval[i] ? o * WBR_GP + 4 * (tid & 15) : (tid % d.Cout) * WBR_GP + WBR_SEG);
+    }
+    const int gcol = 4 * (tid & 15);
+
+    // units in (b, od, segment, oh) order, an XCD a contiguous eighth, a workgroup a contiguous run
+    const int segs = (d.OW + WBR_SEG - 1) / WBR_SEG;
+    const int units = d.B * d.OD * d.OH * segs;
+    const int upx = (units + 7) >> 3;
+    const int xcd = blockIdx.x & 7, nslot = gridDim.x >> 3;
+    const int xfirst = xcd * upx, xn = max(0, min(units, xfirst + upx) - xfirst);
+    const int slot_ = (int)blockIdx.x >> 3;
+    const int ufirst = xfirst + (int)((long long)xn * slot_ / nslot);
+    const int uend = xfirst + (int)((long long)xn * (slot_ + 1) / nslot);
+    const size_t xsample = (size_t)d.Cin * d.D * d.H * d.W, gsample = (size_t)d.Cout * S;
+
+    // where a unit's rows are: the shifted last segment of a row comes first among the stripes of
+    // an (image, plane), as in the row kernel
+    struct Where { int oh, stripe, seg, od, b; };
+    auto locate = [&](Where &u) {
+        const int sq = u.stripe % segs, q_ = u.stripe / segs;
+        u.seg = sq == 0 ? segs - 1 : sq - 1;
+        u.od = q_ % d.OD;
+        u.b = q_ / d.OD;
+    };
+    f32x4 sx[WBS_NX], sg[WBS_NG];
+    auto fetch = [&](const Where &u) {                     // the unit's LAST input row and its gy tile
+        const int ow0 = min(u.seg * WBR_SEG, d.OW - WBR_SEG), xs0 = min(ow0, d.W - WBR_XW);
+        const char *xr = (const char *)(x + (size_t)u.b * xsample + (size_t)((u.od * d.H + u.oh + d.kH - 1) * d.W + xs0));
+        const char *gr = (const char *)(gy + (size_t)u.b * gsample + (size_t)((u.od * d.OH + u.oh) * d.OW + ow0));
+#pragma unroll
+        for (int i = 0; i < WBS_NX; ++i) sx[i] = *(const f32x4a4 *)(xr + xsrc[i]);
+#pragma unroll
+        for (int i = 0; i < WBS_NG; ++i) sg[i] = *(const f32x4a4 *)(gr + gsrc[i]);
+    };
+
+    double dsum[KTW][OTW][4];
+#pragma unroll
+    for (int q = 0; q < KTW; ++q)
+#pragma unroll
+        for (int t = 0; t < OTW; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dsum[q][t][r] = 0.0;
+    double bsum[WBS_NG];
+#pragma unroll
+    for (int i = 0; i < WBS_NG; ++i) bsum[i] = 0.0;
+#ifdef WM_WB_STAMPS
+    unsigned long long t_fill = 0, t_comp = 0, t_b1 = 0, t_wr = 0, t_b2 = 0;
+    const unsigned long long c_begin = WB_CLK(), w_begin = wall_clock64();
+#endif
+
+    Where cur;
+    cur.stripe = ufirst / d.OH;
+    cur.oh = ufirst - cur.stripe * d.OH;
+    locate(cur);
+    int ohm = cur.oh % d.kH;
+    if (ufirst < uend) fetch(cur);
+    for (int ubase = ufirst; ubase < uend; ubase += WBR_FLUSH) {
+        f32x4 acc[KTW][OTW];
+#pragma unroll
+        for (int q = 0; q < KTW; ++q)
+#pragma unroll
+            for (int t = 0; t < OTW; ++t) acc[q][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x2 bacc[WBS_NG];
+#pragma unroll
+        for (int i = 0; i < WBS_NG; ++i) bacc[i] = (f32x2){0.f, 0.f};
+        const int ustop = min(uend, ubase + WBR_FLUSH);
+        for (int unit = ubase; unit < ustop; ++unit) {
+            // the last segment of a row is moved left to end at the row's end; the outputs it then
+            // shares with the segment before are zeroed on their way into the gy tile
+            const int ow0 = min(cur.seg * WBR_SEG, d.OW - WBR_SEG);
+            const int xs0 = min(ow0, d.W - WBR_XW), delta = ow0 - xs0, mzero = cur.seg * WBR_SEG - ow0;
+            int kofd[KTW];
+#pragma unroll
+            for (int q = 0; q < KTW; ++q) kofd[q] = tab[(ohm * KTW + q) * BLOCK];
+#ifdef WM_WB_STAMPS
+            const unsigned long long c0 = WB_CLK();
+#endif
+            __syncthreads();                               // every wave is past its reads of the tile
+#ifdef WM_WB_STAMPS
+            const unsigned long long cA = WB_CLK();
+            t_b1 += cA - c0;
+#endif
+            if (unit == ufirst || cur.oh == 0) {           // top of a run or stripe: the rows above too
+                const char *xr = (const char *)(x + (size_t)cur.b * xsample + (size_t)((cur.od * d.H + cur.oh) * d.W + xs0));
+                for (int kh = 0; kh + 1 < d.kH; ++kh) {
+                    int sl = ohm + kh;
+                    if (sl >= d.kH) sl -= d.kH;
+#pragma unroll
+                    for (int i = 0; i < WBS_NX; ++i)
+                        wm_store4(smem + sl * SS + xdst[i], *(const f32x4a4 *)(xr + (size_t)kh * d.W * sizeof(float) + xsrc[i]));
+                }
+            }
+            {
+                int sl = ohm + d.kH - 1;
+                if (sl >= d.kH) sl -= d.kH;
+#pragma unroll
+                for (int i = 0; i < WBS_NX; ++i) wm_store4(smem + sl * SS + xdst[i], sx[i]);
+                if (mzero > 0) {
+#pragma unroll
+                    for (int i = 0; i < WBS_NG; ++i)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) sg[i][e] = gcol + e < mzero ? 0.0f : sg[i][e];
+                }
+#pragma unroll
+                for (int i = 0; i < WBS_NG; ++i) {
+                    wm_store4(smem + gdst[i], sg[i]);
+                    bacc[i] += (f32x2){sg[i][0], sg[i][1]};
+                    bacc[i] += (f32x2){sg[i][2], sg[i][3]};
+                }
+            }
+#ifdef WM_WB_STAMPS
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            const unsigned long long cB = WB_CLK();
+            t_wr += cB - cA;
+#endif
+            __syncthreads();                               // the tile is in LDS
+#ifdef WM_WB_STAMPS
+            t_b2 += WB_CLK() - cB;
+#endif
+            if (delta) {
+#pragma unroll
+                for (int q = 0; q < KTW; ++q) kofd[q] += delta;
+            }
+            // on to the next unit: its rows travel while this one's MFMAs run
+            if (unit + 1 < uend) {
+                ++cur.oh;
+                if (++ohm == d.kH) ohm = 0;
+                if (cur.oh == d.OH) {
+                    cur.oh = 0;
+                    ohm = 0;
+                    ++cur.stripe;
+                    locate(cur);
+                }
+                fetch(cur);
+            }
+#ifdef WM_WB_STAMPS
+            const unsigned long long c1 = WB_CLK();
+            t_fill += c1 - c0;
+#endif
+            // operands of step s+1 are read while the MFMAs of step s run
+#define WBS_OPS(a_, b_, s_)                                                                  \
+    _Pragma("unroll") for (int t = 0; t < OTW; ++t) a_[t] = smem[abase + t * 16 * WBR_GP + 4 * (s_)]; \
+    _Pragma("unroll") for (int q = 0; q < KTW; ++q) b_[q] = smem[kofd[q] + 4 * (s_)];
+#define WBS_MMA(a_, b_)                                                                      \
+    _Pragma("unroll") for (int q = 0; q < KTW; ++q)                                          \
+        _Pragma("unroll") for (int t = 0; t < OTW; ++t) acc[q][t] = mma(a_[t], b_[q], acc[q][t]);
+            float a0[OTW], b0[KTW], a1[OTW], b1[KTW];
+            // one LDS read behind each of the first MFMAs of a step: a wave alone on its SIMD keeps
+            // the pipe fed while it fetches the next step's operands
+#define WBS_MIX()                                                                            \
+    _Pragma("unroll") for (int m_ = 0; m_ < OTW + KTW; ++m_) {                               \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                   \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                   \
+    }                                                                                        \
+    __builtin_amdgcn_sched_group_barrier(0x008, OTW * KTW, 0);                               \
+    __builtin_amdgcn_sched_barrier(0);
+            WBS_OPS(a0, b0, 0)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s_ = 0; s_ < WBR_SEG / 4; s_ += 2) {
+                WBS_OPS(a1, b1, s_ + 1)
+                WBS_MMA(a0, b0)
+                WBS_MIX()
+                if (s_ + 2 < WBR_SEG / 4) { WBS_OPS(a0, b0, s_ + 2) }
+                WBS_MMA(a1, b1)
+                WBS_MIX()
+            }
+#undef WBS_OPS
+#undef WBS_MIX
+#undef WBS_MMA
+#ifdef WM_WB_STAMPS
+            t_comp += WB_CLK() - c1;
+#endif
+        }
+#pragma unroll
+        for (int q = 0; q < KTW; ++q)
+#pragma unroll
+            for (int t = 0; t < OTW; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dsum[q][t][r] += (double)acc[q][t][r];
+#pragma unroll
+        for (int i = 0; i < WBS_NG; ++i) bsum[i] += (double)bacc[i][0] + (double)bacc[i][1];
+    }
+#ifdef WM_WB_STAMPS
+    if ((tid & 63) == 0 && blockIdx.x < 1024 && wave < 1) {
+        unsigned long long *o = wm_wb_stamps + 8 * blockIdx.x;
+        o[0] = t_fill; o[1] = t_comp; o[2] = t_b1; o[3] = WB_CLK() - c_begin;
+        o[4] = wall_clock64() - w_begin; o[5] = w_begin; o[6] = uend - ufirst; o[7] = (t_wr << 32) | t_b2;
+        wm_wb_stamps[1024 * 8 + blockIdx.x] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID
+    }
+#endif
+#pragma unroll
+    for (int q = 0; q < KTW; ++q) {
+        const int k = (tg * KTW + q) * 16 + j;
+#pragma unroll
+        for (int t = 0; t < OTW; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = (og * OTW + t) * 16 + 4 * g + r;
+                if (k < K && o < d.Cout) slab[(size_t)o * (K + 1) + k] = dsum[q][t][r];
+            }
+    }
+    // a channel's 16 pieces sit in 16 consecutive lanes
+#pragma unroll
+    for (int i = 0; i < WBS_NG; ++i) {
+        double b_ = bsum[i];
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) b_ += __shfl_xor(b_, m);
+        const int o = (tid + BLOCK * i) >> 4;
+        if ((tid & 15) == 0 && gval[i]) slab[(size_t)o * (K + 1) + K] = b_;
     }
 }
 
@@ -1651,6 +1986,82 @@ bool wb_rows_plan(int B, int Cin, int D, int H, int W, int Cout, int kD, int kH,
     return *grid > 0;
 }
 
+// The register-staged row kernel: which split of the 4 waves, its grid and LDS bytes, or false
+// when the shape stays with the kernels above (more than 32 output channels, more than 45 input
+// rows per slot, or float64 sums that do not fit in registers).
+typedef void (*wb_staged_fn)(const float *, const float *, double *, Dims3, int);
+struct WbStagedPlan { wb_staged_fn fn; int grid; size_t lds; };
+
+wb_staged_fn wb_staged_kernel(int otw, int ktw, int wos)
+{
+#define WBS_K(OTW_, WOS_, K_) case K_: return conv3d_bwd_wb_staged_kernel<OTW_, K_, WOS_>;
+    if (wos == 1 && otw == 1) switch (ktw) { WBS_K(1, 1, 1) WBS_K(1, 1, 2) WBS_K(1, 1, 3) WBS_K(1, 1, 4) WBS_K(1, 1, 5) WBS_K(1, 1, 6) WBS_K(1, 1, 7) WBS_K(1, 1, 8) }
+    if (wos == 1 && otw == 2) switch (ktw) { WBS_K(2, 1, 1) WBS_K(2, 1, 2) WBS_K(2, 1, 3) WBS_K(2, 1, 4) WBS_K(2, 1, 5) }
+    if (wos == 2 && otw == 1) switch (ktw) { WBS_K(1, 2, 5) WBS_K(1, 2, 6) WBS_K(1, 2, 7) WBS_K(1, 2, 8) WBS_K(1, 2, 9) }
+#undef WBS_K
+    return nullptr;
+}
+
+bool wb_staged_plan(int B, int Cin, int D, int H, int W, int Cout, int kD, int kH, int kW,
+                    WbStagedPlan *plan)
+{
+    const int OD = D - kD + 1, OH = H - kH + 1, OW = W - kW + 1;
+    const long long Ntot = (long long)B * OD * OH * OW;
+    const int K = Cin * kD * kH * kW, CD = Cin * kD;
+    if (!wb_wide_shape(Ntot, K) || kW - 1 > WBR_XW - WBR_SEG || W < WBR_XW || OW < WBR_SEG) return false;
+    const int otiles = (Cout + 15) / 16, ktiles = (K + 15) / 16;
+#ifdef WM_NO_STAGED
+    return false;
+#endif
+    // 32-bit byte offsets inside a sample
+    if (otiles > 2 || CD * 17 > BLOCK * WBS_NX || (long long)Cin * D * H * W >= (1ll << 30) ||
+        (long long)Cout * OD * OH * OW >= (1ll << 30))
+        return false;
+    // the split with the fewest MFMAs per wave and step
+    wb_staged_fn best = nullptr;
+    int best_work = 1 << 30, best_ktw = 0;
+    for (int wos = 1; wos <= otiles; wos *= 2) {
+        const int otw = otiles / wos, ktw = (ktiles + WAVES / wos - 1) / (WAVES / wos);
+        wb_staged_fn fn = otw * ktw <= 10 ? wb_staged_kernel(otw, ktw, wos) : nullptr;
+        if (fn && otw * ktw < best_work) { best = fn; best_work = otw * ktw; best_ktw = ktw; }
+    }
+    if (!best) return false;
+    const size_t bytes = wbs_lds_bytes(CD, kH, otiles, best_ktw);
+    if (bytes > RESIDENT_LDS) return false;
+    // one occupancy query per (device, kernel, LDS bytes): a host call of microseconds, and not
+    // legal under stream capture
+    struct Slot { const void *fn; size_t lds; int occ; };
+    static std::mutex mu;
+    static Slot slots[64][8] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    int occ = 0;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        Slot *slot = nullptr;
+        for (Slot &c : slots[dev]) {
+            if (c.fn == (const void *)best && c.lds == bytes) { occ = c.occ; break; }
+            if (!c.fn && !slot) slot = &c;
+        }
+        if (!occ) {
+            if (bytes > 64 * 1024 &&
+                hipFuncSetAttribute((const void *)best, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)bytes) != hipSuccess)
+                return false;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, best, BLOCK, bytes) != hipSuccess || occ <= 0)
+                return false;
+            if (slot) { slot->fn = (const void *)best; slot->lds = bytes; slot->occ = occ; }
+        }
+    }
+#ifdef WM_PROBE_ENV
+    if (const char *e = getenv("WM_WB_BPC")) occ = min(occ, atoi(e));
+#endif
+    plan->fn = best;
+    plan->grid = wm_num_cus() * occ & ~7;
+    plan->lds = bytes;
+    return plan->grid > 0;
+}
+
 int fill_dims(Dims3 *d, int B, int Cin, int D, int H, int W, int Cout, int kD, int kH, int kW)
 {
     WM_REQUIRE(B > 0 && Cin > 0 && D > 0 && H > 0 && W > 0 && Cout > 0 && kD > 0 && kH > 0 && kW > 0,
@@ -1876,6 +2287,13 @@ static int conv3d_bwd_data_impl(const float *gy, const float *w, float *gx, cons
     WM_BWD_DATA_DONE("conv3d_bwd_data_kernel");
 }
 
+#ifdef WM_WB_STAMPS
+extern "C" int wm_debug_read_wb_stamps(unsigned long long *out, int n)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(wm_wb_stamps), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1;
+}
+#endif
+
 extern "C" size_t wm_conv3d_bwd_wb_workspace_bytes(int B, int Cin, int D, int H, int W, int Cout,
                                                    int kD, int kH, int kW)
 {
@@ -1888,7 +2306,9 @@ extern "C" size_t wm_conv3d_bwd_wb_workspace_bytes(int B, int Cin, int D, int H,
     if (wb_wide_shape(Ntot, Cin * kD * kH * kW)) splits = (size_t)wm_num_cus() * WB_WIDE_BPC;   // one slab per workgroup
     int rgrid = 0;
     size_t rlds = 0;
-    if (wb_rows_plan(B, Cin, D, H, W, Cout, kD, kH, kW, &rgrid, &rlds)) splits = (size_t)rgrid;
+    WbStagedPlan sp;
+    if (wb_staged_plan(B, Cin, D, H, W, Cout, kD, kH, kW, &sp)) rgrid = sp.grid, splits = (size_t)sp.grid;
+    else if (wb_rows_plan(B, Cin, D, H, W, Cout, kD, kH, kW, &rgrid, &rlds)) splits = (size_t)rgrid;
     int vktw = 0, vgroups = 0;
     size_t vlds = 0;
     if (!rgrid && wb_vol_plan(B, Cin, D, H, W, Cout, kD, kH, kW, &vktw, &vgroups, &vlds))
@@ -1916,6 +2336,17 @@ extern "C" int wm_conv3d_bwd_wb_f32(const float *x, const float *gy, float *gw, 
     const int tiles = ktiles * otiles;
     const int nw = Cout * K, nent = nw + Cout;
     hipStream_t st = (hipStream_t)stream;
+    WbStagedPlan sp;
+    if (wb_staged_plan(B, Cin, D, H, W, Cout, kD, kH, kW, &sp)) {
+        // every workgroup writes its whole slab: no memset
+        hipLaunchKernelGGL(sp.fn, dim3(sp.grid), dim3(BLOCK), sp.lds, st, x, gy, (double *)workspace,
+                           d, K);
+        WM_LAUNCH_CHECK("conv3d_bwd_wb_staged_kernel");
+        hipLaunchKernelGGL(conv3d_reduce_slabs_kernel, dim3((nent + 63) / 64), dim3(1024), 0, st,
+                           (const double *)workspace, sp.grid, Cout, K, gw, gb);
+        WM_LAUNCH_CHECK("conv3d_reduce_slabs_kernel");
+        return WM_OK;
+    }
     int rgrid = 0;
     size_t rlds = 0;
     if (wb_rows_plan(B, Cin, D, H, W, Cout, kD, kH, kW, &rgrid, &rlds)) {
