@@ -745,10 +745,10 @@ def run_conv32(steps, warmup, rank, world, cpu_base, N=8, C=32, H=721, W=1440):
                          "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF,
                          "traffic": pmc_traffic(["conv3d_fwd_rows_kernel<2>",
                                                  "conv3d_bwd_data_rows_kernel<2>",
-                                                 "conv3d_bwd_wb_rows_kernel<2, 5>"],
+                                                 "conv3d_bwd_wb_staged_kernel<1, 9, 2>"],
                                                 (N, C, H, W) == (8, 32, 721, 1440)),
                          "kernel": "conv3d_fwd_rows_kernel + conv3d_bwd_data_rows_kernel + "
-                                   "conv3d_bwd_wb_rows_kernel",
+                                   "conv3d_bwd_wb_staged_kernel",
                          "algorithmic_flops_per_point_per_pass": 2 * C * C * 9,
                          "TFLOPs": {k: flops_pass / (v * 1e-3) / 1e12 for k, v in ms.items()}}}
 
@@ -797,7 +797,7 @@ def run_conv32x3(steps, warmup, rank, world, cpu_base, N=8, C=32, H=721, W=1440,
                                    f"all-reduce"},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF,
                          "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF, "traffic": None,
-                         "kernel": "conv3d_fwd_rows_kernel x3 + conv3d_bwd_wb_rows_kernel x3 + "
+                         "kernel": "conv3d_fwd_rows_kernel x3 + conv3d_bwd_wb_staged_kernel x3 + "
                                    "conv3d_bwd_data_rows_kernel x2 (+ mask, copy, finalize launches "
                                    "inside the bracket)",
                          "algorithmic_flops_per_step": flops}}

@@ -67,6 +67,10 @@ CONV3D_LARGE_CASES = [
     # in registers and take the slab path; depth of one (kD = 1 ring), shifted last segment
     ("rows_slab_sums", 3, 16, (1, 300, 1400), 40, (1, 3, 3), 44, 1),   # 1.25 M outputs
     ("rows_kh1", 2, 16, (1, 500, 1400), 16, (1, 1, 3), 45, 1),         # a ring of one slot: every unit refills
+    # register-staged weight gradient: two channel tiles per wave with a ragged second one and a
+    # ragged tap tile (K = 45); and the 2 x 2 wave split (seven tap tiles per wave, 30 channels)
+    ("staged_ot2", 2, 5, (1, 600, 1000), 24, (1, 3, 3), 46, 1),         # 1.19 M outputs
+    ("staged_w2", 1, 24, (1, 760, 1500), 30, (1, 3, 3), 47, 1),         # 1.14 M outputs
     # small volumes (plane-resident weight gradient): the bias column alone in the last tap tile
     # (K = 16), three channel tiles, planes of 80 positions; and a plane that is not a multiple of 4
     ("vol_bias_tile", 2, 4, (3, 9, 11), 40, (1, 2, 2), 38, 1),

@@ -1421,38 +1421,40 @@ constexpr int WBS_NG = 2;          // the gy tile, 32 channels x 16 pieces
 
 __host__ __device__ inline size_t wbs_lds_bytes(int cd, int kH, int ot, int ktw)
 {
-    return ((size_t)kH * wbr_slot_stride(cd) + (size_t)ot * 16 * WBR_GP + (size_t)kH * ktw * BLOCK) *
-           sizeof(float);
+    return ((size_t)(kH + 1) * wbr_slot_stride(cd) + 2 * (size_t)ot * 16 * WBR_GP) * sizeof(float) +
+           (size_t)(kH + 1) * ktw * BLOCK * sizeof(unsigned short);
 }
 
 template <int OTW, int KTW, int WOS>
-__global__ __launch_bounds__(BLOCK) void conv3d_bwd_wb_staged_kernel(const float *__restrict__ x,
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3d_bwd_wb_staged_kernel(const float *__restrict__ x,
                                                                      const float *__restrict__ gy,
                                                                      double *__restrict__ partial,
                                                                      Dims3 d, int K)
 {
     constexpr int OT = OTW * WOS;
+    constexpr int GSZ = OT * 16 * WBR_GP;                  // words of one gy buffer
     extern __shared__ __align__(16) float smem[];
-    const int CD = d.Cin * d.kD, SS = wbr_slot_stride(CD);
-    // [kH slots][CD][WBR_XP] x | [OT*16][WBR_GP] gy | [kH][KTW][BLOCK] B addresses
-    const int goff = d.kH * SS, toff = goff + OT * 16 * WBR_GP;
+    const int CD = d.Cin * d.kD, SS = wbr_slot_stride(CD), NS = d.kH + 1;
+    // [kH + 1 slots][CD][WBR_XP] x | 2 x [OT*16][WBR_GP] gy | [kH + 1][KTW][BLOCK] B addresses (u16)
+    const int goff = NS * SS, toff = goff + 2 * GSZ;
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int og = wave % WOS, tg = wave / WOS;            // channel-tile group, tap-tile group
     const int S = d.OD * d.OH * d.OW;
     double *slab = partial + (size_t)blockIdx.x * d.Cout * (K + 1);   // [Cout][K + 1], column K = bias
 
-    for (int e = tid; e < goff + OT * 16 * WBR_GP; e += BLOCK) smem[e] = 0.0f;
-    // B operand of tap tile q in phase p (= oh mod kH): tap k = (tg KTW + q) 16 + j =
-    // ((c kD + kd) kH + kh) kW + kw is at word ((kh + p) mod kH) SS + (c kD + kd) WBR_XP + kw + g
-    int *tab = (int *)smem + toff + tid;
+    for (int e = tid; e < toff; e += BLOCK) smem[e] = 0.0f;
+    // B operand of tap tile q in phase p: tap k = (tg KTW + q) 16 + j = ((c kD + kd) kH + kh) kW + kw
+    // is at word ((p + kh) mod (kH + 1)) SS + (c kD + kd) WBR_XP + kw + g
+    unsigned short *tab = (unsigned short *)(smem + toff) + tid;
 #pragma unroll
     for (int q = 0; q < KTW; ++q) {
         int k = (tg * KTW + q) * 16 + j;
         if (k >= K) k = 0;
         const int kw = k % d.kW, r_ = k / d.kW, kh = r_ % d.kH;
         const int w_ = (r_ / d.kH) * WBR_XP + kw + g;
-        for (int p_ = 0; p_ < d.kH; ++p_) tab[(p_ * KTW + q) * BLOCK] = ((kh + p_) % d.kH) * SS + w_;
+        for (int p_ = 0; p_ < NS; ++p_)
+            tab[(p_ * KTW + q) * BLOCK] = (unsigned short)(((kh + p_) % NS) * SS + w_);
     }
     const int abase = goff + (og * OTW * 16 + j) * WBR_GP + g;
 
@@ -1492,24 +1494,63 @@ __global__ __launch_bounds__(BLOCK) void conv3d_bwd_wb_staged_kernel(const float
     const int uend = xfirst + (int)((long long)xn * (slot_ + 1) / nslot);
     const size_t xsample = (size_t)d.Cin * d.D * d.H * d.W, gsample = (size_t)d.Cout * S;
 
-    // where a unit's rows are: the shifted last segment of a row comes first among the stripes of
-    // an (image, plane), as in the row kernel
-    struct Where { int oh, stripe, seg, od, b; };
-    auto locate = [&](Where &u) {
-        const int sq = u.stripe % segs, q_ = u.stripe / segs;
-        u.seg = sq == 0 ? segs - 1 : sq - 1;
-        u.od = q_ % d.OD;
-        u.b = q_ / d.OD;
+    // where a unit's rows are.  sq counts the stripes of an (image, plane); the shifted last
+    // segment of a row comes first among them, as in the row kernel.  ow0: first output column
+    // (the last segment is moved left to end at the row's end; the outputs it then shares with the
+    // segment before are zeroed on their way into the gy tile: mz of them), xs0: first input column.
+    // All of it is wave-uniform and branch-free: it is scheduled between the MFMAs of a step.
+    struct Cur { int oh, sq, od, b, ow0, xs0, mz; };
+    auto derive = [&](Cur &c) {
+        const int seg = c.sq == 0 ? segs - 1 : c.sq - 1;
+        c.ow0 = min(seg * WBR_SEG, d.OW - WBR_SEG);
+        c.xs0 = min(c.ow0, d.W - WBR_XW);
+        c.mz = seg * WBR_SEG - c.ow0;
+    };
+    auto locate = [&](Cur &c, int unit) {
+        const int stripe = unit / d.OH, q_ = stripe / segs;
+        c.oh = unit - stripe * d.OH;
+        c.sq = stripe - q_ * segs;
+        c.od = q_ % d.OD;
+        c.b = q_ / d.OD;
+        derive(c);
+    };
+    auto advance = [&](Cur &c, int by) {                   // by = 0: stay
+        c.oh += by;
+        const int w0 = c.oh == d.OH;
+        c.oh = w0 ? 0 : c.oh;
+        c.sq += w0;
+        const int w1 = c.sq == segs;
+        c.sq = w1 ? 0 : c.sq;
+        c.od += w1;
+        const int w2 = c.od == d.OD;
+        c.od = w2 ? 0 : c.od;
+        c.b += w2;
+        derive(c);
     };
     f32x4 sx[WBS_NX], sg[WBS_NG];
-    auto fetch = [&](const Where &u) {                     // the unit's LAST input row and its gy tile
-        const int ow0 = min(u.seg * WBR_SEG, d.OW - WBR_SEG), xs0 = min(ow0, d.W - WBR_XW);
-        const char *xr = (const char *)(x + (size_t)u.b * xsample + (size_t)((u.od * d.H + u.oh + d.kH - 1) * d.W + xs0));
-        const char *gr = (const char *)(gy + (size_t)u.b * gsample + (size_t)((u.od * d.OH + u.oh) * d.OW + ow0));
+    auto fetch = [&](const Cur &c) {                       // the unit's LAST input row and its gy tile
+        const char *xr = (const char *)(x + (size_t)c.b * xsample + (size_t)((c.od * d.H + c.oh + d.kH - 1) * d.W + c.xs0));
+        const char *gr = (const char *)(gy + (size_t)c.b * gsample + (size_t)((c.od * d.OH + c.oh) * d.OW + c.ow0));
 #pragma unroll
         for (int i = 0; i < WBS_NX; ++i) sx[i] = *(const f32x4a4 *)(xr + xsrc[i]);
 #pragma unroll
         for (int i = 0; i < WBS_NG; ++i) sg[i] = *(const f32x4a4 *)(gr + gsrc[i]);
+    };
+    f32x2 bacc[WBS_NG];
+#pragma unroll
+    for (int i = 0; i < WBS_NG; ++i) bacc[i] = (f32x2){0.f, 0.f};
+    // stage registers -> ring slot and gy buffer; the tile counts `live` (0 or 1) times in the bias
+    auto put = [&](int slot, int par, int mz, float live) {
+#pragma unroll
+        for (int i = 0; i < WBS_NX; ++i) wm_store4(smem + slot * SS + xdst[i], sx[i]);
+#pragma unroll
+        for (int i = 0; i < WBS_NG; ++i) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sg[i][e] = gcol + e < mz ? 0.0f : sg[i][e];
+            wm_store4(smem + par * GSZ + gdst[i], sg[i]);
+            bacc[i] += live * (f32x2){sg[i][0], sg[i][1]};
+            bacc[i] += live * (f32x2){sg[i][2], sg[i][3]};
+        }
     };
 
     double dsum[KTW][OTW][4];
@@ -1522,149 +1563,168 @@ __global__ __launch_bounds__(BLOCK) void conv3d_bwd_wb_staged_kernel(const float
     double bsum[WBS_NG];
 #pragma unroll
     for (int i = 0; i < WBS_NG; ++i) bsum[i] = 0.0;
+    f32x4 acc[KTW][OTW];
+#pragma unroll
+    for (int q = 0; q < KTW; ++q)
+#pragma unroll
+        for (int t = 0; t < OTW; ++t) acc[q][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #ifdef WM_WB_STAMPS
-    unsigned long long t_fill = 0, t_comp = 0, t_b1 = 0, t_wr = 0, t_b2 = 0;
+    unsigned long long t_top = 0;
     const unsigned long long c_begin = WB_CLK(), w_begin = wall_clock64();
 #endif
 
-    Where cur;
-    cur.stripe = ufirst / d.OH;
-    cur.oh = ufirst - cur.stripe * d.OH;
-    locate(cur);
-    int ohm = cur.oh % d.kH;
-    if (ufirst < uend) fetch(cur);
-    for (int ubase = ufirst; ubase < uend; ubase += WBR_FLUSH) {
-        f32x4 acc[KTW][OTW];
+    if (ufirst < uend) {
+        // tile(ufirst): its last row and gy tile; then tile(ufirst + 1) into the stage registers.
+        // cf: the unit whose rows were fetched last; mz1, dl1, top1: of the unit after this one
+        Cur cf;
+        locate(cf, ufirst);
+        int p = 0, par = 0;
+        fetch(cf);
+        put(d.kH - 1, 0, cf.mz, 1.0f);
+        int kofd[KTW];
 #pragma unroll
-        for (int q = 0; q < KTW; ++q)
-#pragma unroll
-            for (int t = 0; t < OTW; ++t) acc[q][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        f32x2 bacc[WBS_NG];
-#pragma unroll
-        for (int i = 0; i < WBS_NG; ++i) bacc[i] = (f32x2){0.f, 0.f};
-        const int ustop = min(uend, ubase + WBR_FLUSH);
-        for (int unit = ubase; unit < ustop; ++unit) {
-            // the last segment of a row is moved left to end at the row's end; the outputs it then
-            // shares with the segment before are zeroed on their way into the gy tile
-            const int ow0 = min(cur.seg * WBR_SEG, d.OW - WBR_SEG);
-            const int xs0 = min(ow0, d.W - WBR_XW), delta = ow0 - xs0, mzero = cur.seg * WBR_SEG - ow0;
-            int kofd[KTW];
-#pragma unroll
-            for (int q = 0; q < KTW; ++q) kofd[q] = tab[(ohm * KTW + q) * BLOCK];
+        for (int q = 0; q < KTW; ++q) kofd[q] = (int)tab[q * BLOCK] + (cf.ow0 - cf.xs0);
+        advance(cf, ufirst + 1 < uend);
+        fetch(cf);
+        int mz1 = cf.mz, dl1 = cf.ow0 - cf.xs0;
+        bool top1 = cf.oh == 0;
+        int ab = abase;
+        bool top = true;
+        int nfl = 0;
+        // B operands are read one step ahead, the channel operand (which every MFMA of a step needs)
+        // two steps ahead into a ring of four, so no MFMA waits for a read issued just before it
+        float aq[4][OTW], b0[KTW], b1[KTW];
+#define WBS_OPSB(b_, s_, KO)                                                                 \
+    _Pragma("unroll") for (int q = 0; q < KTW; ++q) b_[q] = smem[KO[q] + 4 * (s_)];
+#define WBS_OPSA(r_, s_, AB)                                                                 \
+    _Pragma("unroll") for (int t = 0; t < OTW; ++t) aq[r_][t] = smem[AB + t * 16 * WBR_GP + 4 * (s_)];
+#define WBS_MMA(r_, b_)                                                                      \
+    _Pragma("unroll") for (int q = 0; q < KTW; ++q)                                          \
+        _Pragma("unroll") for (int t = 0; t < OTW; ++t) acc[q][t] = mma(aq[r_][t], b_[q], acc[q][t]);
+        // behind every MFMA of a step: R LDS reads, V VALU, S SALU, M global loads, W LDS writes of
+        // whatever else the step carries, so that a wave alone on its SIMD keeps the pipe fed
+#define WBS_MIX(R, V, S, M, W)                                                               \
+    _Pragma("unroll") for (int m_ = 0; m_ < OTW * KTW; ++m_) {                               \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                   \
+        if (R) __builtin_amdgcn_sched_group_barrier(0x100, R, 0);                            \
+        if (V) __builtin_amdgcn_sched_group_barrier(0x002, V, 0);                            \
+        if (S) __builtin_amdgcn_sched_group_barrier(0x004, S, 0);                            \
+        if (M) __builtin_amdgcn_sched_group_barrier(0x020, M, 0);                            \
+        if (W) __builtin_amdgcn_sched_group_barrier(0x200, W, 0);                            \
+    }                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);
+        for (int unit = ufirst; unit < uend; ++unit) {
+            const bool has1 = unit + 1 < uend, has2 = unit + 2 < uend;
+            if (top) {
+                // top of a run or stripe: the kH - 1 rows above the staged one, once every wave
+                // is through with the unit before; no operands were read ahead
 #ifdef WM_WB_STAMPS
-            const unsigned long long c0 = WB_CLK();
+                const unsigned long long ct = WB_CLK();
 #endif
-            __syncthreads();                               // every wave is past its reads of the tile
-#ifdef WM_WB_STAMPS
-            const unsigned long long cA = WB_CLK();
-            t_b1 += cA - c0;
-#endif
-            if (unit == ufirst || cur.oh == 0) {           // top of a run or stripe: the rows above too
-                const char *xr = (const char *)(x + (size_t)cur.b * xsample + (size_t)((cur.od * d.H + cur.oh) * d.W + xs0));
+                __syncthreads();
+                Cur c0;
+                locate(c0, unit);
+                const char *xr = (const char *)(x + (size_t)c0.b * xsample + (size_t)((c0.od * d.H + c0.oh) * d.W + c0.xs0));
                 for (int kh = 0; kh + 1 < d.kH; ++kh) {
-                    int sl = ohm + kh;
-                    if (sl >= d.kH) sl -= d.kH;
+                    int sl = p + kh;
+                    if (sl >= NS) sl -= NS;
+                    f32x4 row[WBS_NX];
 #pragma unroll
                     for (int i = 0; i < WBS_NX; ++i)
-                        wm_store4(smem + sl * SS + xdst[i], *(const f32x4a4 *)(xr + (size_t)kh * d.W * sizeof(float) + xsrc[i]));
+                        row[i] = *(const f32x4a4 *)(xr + (size_t)kh * d.W * sizeof(float) + xsrc[i]);
+#pragma unroll
+                    for (int i = 0; i < WBS_NX; ++i) wm_store4(smem + sl * SS + xdst[i], row[i]);
                 }
-            }
-            {
-                int sl = ohm + d.kH - 1;
-                if (sl >= d.kH) sl -= d.kH;
-#pragma unroll
-                for (int i = 0; i < WBS_NX; ++i) wm_store4(smem + sl * SS + xdst[i], sx[i]);
-                if (mzero > 0) {
-#pragma unroll
-                    for (int i = 0; i < WBS_NG; ++i)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) sg[i][e] = gcol + e < mzero ? 0.0f : sg[i][e];
-                }
-#pragma unroll
-                for (int i = 0; i < WBS_NG; ++i) {
-                    wm_store4(smem + gdst[i], sg[i]);
-                    bacc[i] += (f32x2){sg[i][0], sg[i][1]};
-                    bacc[i] += (f32x2){sg[i][2], sg[i][3]};
-                }
-            }
+                __syncthreads();
+                WBS_OPSB(b0, 0, kofd)
+                WBS_OPSA(0, 0, ab)
+                WBS_OPSA(1, 1, ab)
+                __builtin_amdgcn_sched_barrier(0);
 #ifdef WM_WB_STAMPS
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            const unsigned long long cB = WB_CLK();
-            t_wr += cB - cA;
+                t_top += WB_CLK() - ct;
 #endif
-            __syncthreads();                               // the tile is in LDS
-#ifdef WM_WB_STAMPS
-            t_b2 += WB_CLK() - cB;
-#endif
-            if (delta) {
-#pragma unroll
-                for (int q = 0; q < KTW; ++q) kofd[q] += delta;
             }
-            // on to the next unit: its rows travel while this one's MFMAs run
-            if (unit + 1 < uend) {
-                ++cur.oh;
-                if (++ohm == d.kH) ohm = 0;
-                if (cur.oh == d.OH) {
-                    cur.oh = 0;
-                    ohm = 0;
-                    ++cur.stripe;
-                    locate(cur);
-                }
-                fetch(cur);
-            }
-#ifdef WM_WB_STAMPS
-            const unsigned long long c1 = WB_CLK();
-            t_fill += c1 - c0;
-#endif
-            // operands of step s+1 are read while the MFMAs of step s run
-#define WBS_OPS(a_, b_, s_)                                                                  \
-    _Pragma("unroll") for (int t = 0; t < OTW; ++t) a_[t] = smem[abase + t * 16 * WBR_GP + 4 * (s_)]; \
-    _Pragma("unroll") for (int q = 0; q < KTW; ++q) b_[q] = smem[kofd[q] + 4 * (s_)];
-#define WBS_MMA(a_, b_)                                                                      \
-    _Pragma("unroll") for (int q = 0; q < KTW; ++q)                                          \
-        _Pragma("unroll") for (int t = 0; t < OTW; ++t) acc[q][t] = mma(a_[t], b_[q], acc[q][t]);
-            float a0[OTW], b0[KTW], a1[OTW], b1[KTW];
-            // one LDS read behind each of the first MFMAs of a step: a wave alone on its SIMD keeps
-            // the pipe fed while it fetches the next step's operands
-#define WBS_MIX()                                                                            \
-    _Pragma("unroll") for (int m_ = 0; m_ < OTW + KTW; ++m_) {                               \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                   \
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                   \
-    }                                                                                        \
-    __builtin_amdgcn_sched_group_barrier(0x008, OTW * KTW, 0);                               \
-    __builtin_amdgcn_sched_barrier(0);
-            WBS_OPS(a0, b0, 0)
-            __builtin_amdgcn_sched_barrier(0);
+            int p1 = p + 1;
+            p1 = p1 == NS ? 0 : p1;
+            int mz2 = 0, dl2 = 0;
+            bool top2 = false;
 #pragma unroll
             for (int s_ = 0; s_ < WBR_SEG / 4; s_ += 2) {
-                WBS_OPS(a1, b1, s_ + 1)
-                WBS_MMA(a0, b0)
-                WBS_MIX()
-                if (s_ + 2 < WBR_SEG / 4) { WBS_OPS(a0, b0, s_ + 2) }
-                WBS_MMA(a1, b1)
-                WBS_MIX()
+                // ---- step s_
+                WBS_OPSB(b1, s_ + 1, kofd)
+                if (s_ + 2 < WBR_SEG / 4) {
+                    WBS_OPSA((s_ + 2) & 3, s_ + 2, ab)
+                } else {
+                    // every read of this unit has been issued: on to the next unit's addresses and
+                    // first operands (read again above when it is a top)
+                    ab = abase + (par ^ 1) * GSZ;
+                    WBS_OPSA(0, 0, ab)
+#pragma unroll
+                    for (int q = 0; q < KTW; ++q) kofd[q] = (int)tab[(p1 * KTW + q) * BLOCK];
+                }
+                if (s_ == 6) put(p == 0 ? NS - 1 : p - 1, par ^ 1, mz1, has1 ? 1.0f : 0.0f);
+                if (s_ == 12) {                            // the rows of unit + 2 set out
+                    advance(cf, has2);
+                    fetch(cf);
+                    mz2 = cf.mz;
+                    dl2 = cf.ow0 - cf.xs0;
+                    top2 = cf.oh == 0;
+                }
+                WBS_MMA(s_ & 3, b0)
+                if (s_ == 6) { WBS_MIX(1, 3, 1, 0, 1) }
+                else if (s_ == 12) { WBS_MIX(1, 1, 5, 1, 0) }
+                else if (s_ == 14) { WBS_MIX(2, 1, 0, 0, 0) }
+                else { WBS_MIX(1, 0, 0, 0, 0) }
+                // ---- step s_ + 1
+                if (s_ == 4) __syncthreads();              // every wave is through with the unit before: its
+                                                           // first row's slot and its gy buffer are free
+                if (s_ == 10) __syncthreads();             // tile(unit + 1) is in LDS
+                if (s_ + 2 < WBR_SEG / 4) {
+                    WBS_OPSB(b0, s_ + 2, kofd)
+                    WBS_OPSA((s_ + 3) & 3, s_ + 3, ab)
+                } else {
+#pragma unroll
+                    for (int q = 0; q < KTW; ++q) kofd[q] += dl1;
+                    WBS_OPSB(b0, 0, kofd)
+                    WBS_OPSA(1, 1, ab)
+                }
+                WBS_MMA((s_ + 1) & 3, b1)
+                if (s_ == 14) { WBS_MIX(1, 1, 0, 0, 0) }
+                else { WBS_MIX(1, 0, 0, 0, 0) }
             }
-#undef WBS_OPS
-#undef WBS_MIX
-#undef WBS_MMA
-#ifdef WM_WB_STAMPS
-            t_comp += WB_CLK() - c1;
-#endif
+            if (++nfl == WBR_FLUSH || !has1) {             // 1024 outputs of fp32 accumulation
+                nfl = 0;
+#pragma unroll
+                for (int q = 0; q < KTW; ++q)
+#pragma unroll
+                    for (int t = 0; t < OTW; ++t) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) dsum[q][t][r] += (double)acc[q][t][r];
+                        acc[q][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    }
+#pragma unroll
+                for (int i = 0; i < WBS_NG; ++i) {
+                    bsum[i] += (double)bacc[i][0] + (double)bacc[i][1];
+                    bacc[i] = (f32x2){0.f, 0.f};
+                }
+            }
+            top = has1 && top1;
+            top1 = top2;
+            mz1 = mz2;
+            dl1 = dl2;
+            p = p1;
+            par ^= 1;
         }
-#pragma unroll
-        for (int q = 0; q < KTW; ++q)
-#pragma unroll
-            for (int t = 0; t < OTW; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) dsum[q][t][r] += (double)acc[q][t][r];
-#pragma unroll
-        for (int i = 0; i < WBS_NG; ++i) bsum[i] += (double)bacc[i][0] + (double)bacc[i][1];
+#undef WBS_OPSA
+#undef WBS_OPSB
+#undef WBS_MMA
+#undef WBS_MIX
     }
 #ifdef WM_WB_STAMPS
     if ((tid & 63) == 0 && blockIdx.x < 1024 && wave < 1) {
         unsigned long long *o = wm_wb_stamps + 8 * blockIdx.x;
-        o[0] = t_fill; o[1] = t_comp; o[2] = t_b1; o[3] = WB_CLK() - c_begin;
-        o[4] = wall_clock64() - w_begin; o[5] = w_begin; o[6] = uend - ufirst; o[7] = (t_wr << 32) | t_b2;
+        o[0] = t_top; o[1] = 0; o[2] = 0; o[3] = WB_CLK() - c_begin;
+        o[4] = wall_clock64() - w_begin; o[5] = w_begin; o[6] = uend - ufirst; o[7] = 0;
         wm_wb_stamps[1024 * 8 + blockIdx.x] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID
     }
 #endif
@@ -2027,7 +2087,8 @@ bool wb_staged_plan(int B, int Cin, int D, int H, int W, int Cout, int kD, int k
     }
     if (!best) return false;
     const size_t bytes = wbs_lds_bytes(CD, kH, otiles, best_ktw);
-    if (bytes > RESIDENT_LDS) return false;
+    // B addresses are 16-bit words of the ring
+    if (bytes > 80 * 1024 || (kH + 1) * wbr_slot_stride(CD) >= (1 << 16)) return false;
     // one occupancy query per (device, kernel, LDS bytes): a host call of microseconds, and not
     // legal under stream capture
     struct Slot { const void *fn; size_t lds; int occ; };
