@@ -760,15 +760,27 @@ __global__ __launch_bounds__(BLOCK) void conv3d_bwd_data_wide_kernel(const float
 // Input gradient with the tiling of conv3d_fwd_rows_kernel: a wave's unit is 64 consecutive
 // positions of one row of gx.  Units whose every tap is in range for every lane (all but the
 // first/last kH-1 rows and the first and last segment of a row) take the unmasked path; border
-// units evaluate the range per tap and lane.  Tap offsets into gy are negative-going and kept as
-// wrapped 32-bit byte offsets.
+// units evaluate the range per tap and lane (MASKED 2), or only the columns of the first and last
+// chunk when the rows are in range (MASKED 1).  Tap offsets into gy are negative-going and kept
+// as wrapped 32-bit byte offsets.
 #define ROWSB_LOAD(dst, sbase)                                                         \
     _Pragma("unroll") for (int u = 0; u < UNR; ++u) {                                  \
         const int k4_ = 4 * ((sbase) + u) + g;                                         \
         const unsigned a_ = lane0 + off[k4_];                                          \
-        if (!MASKED) {                                                                 \
+        if (MASKED == 0) {                                                             \
             _Pragma("unroll") for (int c = 0; c < CPW; ++c)                            \
                 dst[u][c] = *(const float *)(gb + a_ + 64u * c);                       \
+        } else if (MASKED == 1) {       /* rows in range; columns: first and last chunk only */ \
+            const int wq_ = w0 + j - (int)(tap[k4_] & 255u);                           \
+            _Pragma("unroll") for (int c = 0; c < CPW; ++c) {                          \
+                if (c == 0 || c == CPW - 1) {                                          \
+                    const bool ok_ = (unsigned)(wq_ + 16 * c) < (unsigned)d.OW;        \
+                    const float v_ = *(const float *)(gb + (ok_ ? a_ + 64u * c : 0u)); \
+                    dst[u][c] = ok_ ? v_ : 0.0f;                                       \
+                } else {            /* a_ may be a wrapped negative: add in 32 bits */  \
+                    dst[u][c] = *(const float *)(gb + (a_ + 64u * c));                 \
+                }                                                                      \
+            }                                                                          \
         } else {                                                                       \
             const unsigned tp_ = tap[k4_];                                             \
             const bool rv_ = (unsigned)(dz - (int)(tp_ >> 16)) < (unsigned)d.OD &&     \
@@ -782,7 +794,7 @@ __global__ __launch_bounds__(BLOCK) void conv3d_bwd_data_wide_kernel(const float
         }                                                                              \
     }
 
-template <int CT, bool MASKED>
+template <int CT, int MASKED>
 __device__ __forceinline__ void bwd_rows_unit(const char *gb, const float *wl, const unsigned *off,
                                               const unsigned *tap, const Dims3 &d, int steps,
                                               unsigned lane0, int dz, int h, int w0, int lane,
@@ -864,12 +876,17 @@ __global__ __launch_bounds__(BLOCK) void conv3d_bwd_data_rows_kernel(const float
         for (int c = 0; c < CPW; ++c)
 #pragma unroll
             for (int t = 0; t < CT; ++t) acc[c][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const bool interior = dz >= d.kD - 1 && dz < d.OD && h >= d.kH - 1 && h < d.OH &&
-                              w0 >= d.kW - 1 && w0 + ROWS_SEG <= d.OW;
-        if (interior)
-            bwd_rows_unit<CT, false>(gb, wl, off, tap, d, steps, lane0, dz, h, w0, lane, acc);
+        // the first and last segment of a row (2 of 23 units at 1440 columns) leave the row only in
+        // their first and last 16 columns as long as kW <= 17: one compare and two selects per tap
+        // for those chunks instead of the full range test for all four
+        const bool rows_in = dz >= d.kD - 1 && dz < d.OD && h >= d.kH - 1 && h < d.OH;
+        const bool cols_in = w0 >= d.kW - 1 && w0 + ROWS_SEG <= d.OW;
+        if (rows_in && cols_in)
+            bwd_rows_unit<CT, 0>(gb, wl, off, tap, d, steps, lane0, dz, h, w0, lane, acc);
+        else if (rows_in && d.kW <= 17 && CPW >= 2)
+            bwd_rows_unit<CT, 1>(gb, wl, off, tap, d, steps, lane0, dz, h, w0, lane, acc);
         else
-            bwd_rows_unit<CT, true>(gb, wl, off, tap, d, steps, lane0, dz, h, w0, lane, acc);
+            bwd_rows_unit<CT, 2>(gb, wl, off, tap, d, steps, lane0, dz, h, w0, lane, acc);
 
         char *xb = (char *)(gx + (size_t)b_ * gxsample);
         const unsigned sp0 = 4u * ((unsigned)((dz * d.H + h) * d.W + w0 + j) + (unsigned)(4 * g) * V);
