@@ -485,7 +485,8 @@ def run_conv(steps, warmup, rank, world, cpu_base, N=64, H=721, W=1440):
                      "traffic": pmc_traffic(kernels, default_shape),
                      "traffic_source": pmc_source(kernels, default_shape),
                      "kernel": "conv_fwd_c1f_kernel<3,3> + conv_bwd_wb_c1f_kernel<3,3> (the "
-                               "weight-gradient finalize runs inside the backward kernel); "
+                               "weight-gradient finalize launch is inside the backward call and "
+                               "its time is counted); "
                                "duration = HIP-event time of the timed region / steps",
                      "fwd_GBs": fwd_bytes / (fwd_ms * 1e-3) / 1e9,
                      "bwd_wb_GBs": bwd_bytes / (bwd_ms * 1e-3) / 1e9,
@@ -700,6 +701,33 @@ def run_model(steps, warmup, rank, world, cpu_base, B=721 * 1440):
 
 
 # ------------------------------------------------------------------------------ 32-channel conv
+def conv_stack_cpu_library(ws, bs, x1, g1, relu, reps=5):
+    """Library CPU baseline of the 32-channel layers: torch.nn.functional.conv2d (+ ReLU) forward and
+    torch.autograd.grad of the weights, biases and the input on ONE image of the GPU run's data."""
+    nthr = cpu_threads()
+    torch.set_num_threads(nthr)
+    ws = [t.clone().requires_grad_(True) for t in ws]
+    bs = [t.clone().requires_grad_(True) for t in bs]
+    xin = x1.clone().requires_grad_(True)
+
+    def one():
+        h = xin
+        for wl, bl in zip(ws, bs):
+            h = torch.nn.functional.conv2d(h, wl, bl)
+            if relu:
+                h = torch.relu(h)
+        torch.autograd.grad(h, [xin] + ws + bs, g1)
+
+    one()
+    t, n = median_time(one, 8.0, min_reps=3, max_reps=reps)
+    pts = x1.shape[0] * x1.shape[2] * x1.shape[3]
+    return {"value": pts / t, "unit": "grid-pts/s", "cores": nthr, "kind": "library",
+            "cpu": cpu_model_name(),
+            "sample": f"1 of the images per GPU: torch.nn.functional.conv2d"
+                      f"{' + relu' if relu else ''} x{len(ws)} forward + torch.autograd.grad(input, "
+                      f"weights, biases) on CPU tensors, {nthr} threads, median of {n}"}
+
+
 def run_conv32(steps, warmup, rank, world, cpu_base, N=8, C=32, H=721, W=1440):
     """BASELINE configs[3] read literally (4b): one Conv(32->32, 3x3) layer on (N,32,721,1440),
     forward + backward(data, weight, bias) -- the implicit-GEMM MFMA kernels."""
@@ -737,7 +765,11 @@ def run_conv32(steps, warmup, rank, world, cpu_base, N=8, C=32, H=721, W=1440):
     pts = N * H * W
     flops_pass = 2.0 * C * C * 9 * N * (H - 2) * (W - 2)
     ach = 3 * flops_pass / (sum(ms.values()) * 1e-3) / 1e12
-    return {"value": pts * world * steps / total, "unit": "grid-pts/s",
+    base = None
+    if cpu_base and rank == 0 and world == 1:
+        base = conv_stack_cpu_library([w.cpu()], [b.cpu()], x[:1].cpu(), gy[:1].cpu(), relu=False)
+    return {**({"cpu_baseline": base} if base else {}),
+            "value": pts * world * steps / total, "unit": "grid-pts/s",
             "ms_per_step": total / steps * 1e3, "kernel_ms": ms,
             "config": {"workload": f"Conv2d({C}->{C}, 3x3) fwd + bwd(data, weight, bias) on "
                                    f"({N},{C},{H},{W}) per GPU"},
@@ -788,7 +820,12 @@ def run_conv32x3(steps, warmup, rank, world, cpu_base, N=8, C=32, H=721, W=1440,
             flops += 2.0 * C * C * 9 * out_pos          # executed over the outputs of layer l
     ach = flops / (ms * 1e-3) / 1e12
     clipped = float((st.h[L] == 0).float().mean())
-    return {"value": N * H * W * world * steps / total, "unit": "grid-pts/s",
+    base = None
+    if cpu_base and rank == 0 and world == 1:
+        base = conv_stack_cpu_library([t.cpu() for t in ws], [t.cpu() for t in bs], x[:1].cpu(),
+                                      gout[:1].cpu(), relu=True, reps=3)
+    return {**({"cpu_baseline": base} if base else {}),
+            "value": N * H * W * world * steps / total, "unit": "grid-pts/s",
             "ms_per_step": total / steps * 1e3, "step_kernels_ms": ms,
             "relu_clipped_fraction_last_layer": clipped,
             "grad_floats_all_reduced": int(st.flat_grads.numel()),
@@ -1051,6 +1088,8 @@ def main():
                         "value": cres["value"], "ms_per_step": cres["ms_per_step"],
                         "roofline": cres["roofline"], "config": cres["config"],
                         "kernel_ms": cres["kernel_ms"]})
+            if cres.get("cpu_baseline"):
+                out["cpu_baseline"] = cres["cpu_baseline"]
         else:
             out.setdefault("also", {})["conv32"] = cres
     if args.workload in ("all", "conv32x3"):
@@ -1062,6 +1101,8 @@ def main():
             out.update({"metric": "grid-pts/s 3-layer conv32 model fwd+bwd", "unit": "grid-pts/s",
                         "value": sres["value"], "ms_per_step": sres["ms_per_step"],
                         "roofline": sres["roofline"], "config": sres["config"]})
+            if sres.get("cpu_baseline"):
+                out["cpu_baseline"] = sres["cpu_baseline"]
         else:
             out.setdefault("also", {})["conv32x3"] = sres
     if args.workload in ("all", "fields"):
