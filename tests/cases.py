@@ -79,6 +79,11 @@ CONV3D_LARGE_CASES = [
     # second layer at batch 12; and two input-channel tiles with a ragged last one)
     ("mid_bwd_data", 12, 16, (7, 7, 14), 64, (5, 5, 5), 40, 1),
     ("mid_ct2", 3, 20, (8, 20, 20), 40, (3, 3, 3), 41, 1),
+    # rows of <= 16 positions with mostly out-of-range taps: the row-tile backward-data kernel
+    # (ragged channel tiles and channel groups, kW < 4; four channel tiles, kW = 6, full-width rows)
+    ("rowtap_ragged", 3, 20, (5, 6, 11), 6, (4, 4, 3), 48, 1),
+    ("rowtap_ct4", 2, 50, (6, 7, 16), 9, (4, 5, 6), 49, 1),
+    ("rowtap_two_odd", 11, 16, (7, 7, 14), 20, (5, 5, 5), 50, 1),   # two batch items per workgroup, odd batch
     # >= 128 output planes with weights + slab resident in LDS: the plane-resident forward kernel
     ("vol_fwd", 10, 1, (20, 20, 20), 32, (7, 7, 7), 42, 1),
     ("vol_fwd_ragged", 9, 3, (18, 9, 13), 20, (3, 2, 4), 43, 1),

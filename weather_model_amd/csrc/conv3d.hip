@@ -660,6 +660,112 @@ __global__ __launch_bounds__(NW * 64) void conv3d_bwd_data_tap_kernel(const floa
     }
 }
 
+// ------------------------------------------------------------------------------ backward data, row tiles
+// Small volumes with large kernels (the reference's second layer: (16,16,7,7,14) <- (16,64,3,3,10),
+// 5^3): an input position meets an output position for 13 % of the taps only, and the tap-order
+// kernel above, which drops 16-tap chunks without a live tap, still walks half of them.  Here a
+// workgroup owns ONE ROW (b, z, y) of gx (W <= 16 positions): the taps (kd, kh) whose output plane
+// and row exist are the same for the whole row, so exactly those are walked -- (OD/D)(OH/H) of
+// the kD kH pairs, 18 % for that layer -- and only the kw range is masked per lane.  One MFMA
+// step contracts four output channels at one tap (lane group g <-> channel o0 + g), so a lane's
+// weights for the kW taps of (o, c, kd, kh) are consecutive floats (one 16-byte load for the
+// first four) and its gy values are one row shifted by kw.  The NW waves take (pair, channel
+// group) super-steps round-robin; the partial tiles are summed through LDS in a fixed order.
+template <int CT, int NW, int NB>
+__global__ __launch_bounds__(NW * 64) void conv3d_bwd_data_rowtap_kernel(const float *__restrict__ gy,
+                                                                       const float *__restrict__ w,
+                                                                       float *__restrict__ gx, Dims3 d)
+{
+    // NB batch items share a workgroup: the weights of a super-step are gathered once (20 useful
+    // bytes of every 128-byte line they touch: the gathers, served by L2, are what the kernel
+    // waits for) and multiplied with NB rows of gy
+    __shared__ float part[NW * CT * 256];
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int k3 = d.kD * d.kH * d.kW;
+    const int S = d.OD * d.OH * d.OW, V = d.D * d.H * d.W;
+    const int row = blockIdx.x, y_ = row % d.H, q_ = row / d.H, z = q_ % d.D, b0 = (q_ / d.D) * NB;
+    const int kd0 = max(0, z - d.OD + 1), kd1 = min(d.kD - 1, z);
+    const int kh0 = max(0, y_ - d.OH + 1), kh1 = min(d.kH - 1, y_);
+    const int nkh = kh1 - kh0 + 1, npair = (kd1 - kd0 + 1) * nkh;
+    const int ogrp = (d.Cout + 3) >> 2, nsup = npair * ogrp;
+    const size_t gstep = (size_t)d.Cout * S;               // one batch item of gy
+    f32x4 acc[NB][CT];
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+        for (int t = 0; t < CT; ++t) acc[n][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bool bv[NB];
+#pragma unroll
+    for (int n = 0; n < NB; ++n) bv[n] = b0 + n < d.B;
+    for (int sp = wave; sp < nsup; sp += NW) {
+        const int pair = sp / ogrp, o = (sp - pair * ogrp) * 4 + g;
+        const int kd = kd0 + pair / nkh, kh = kh0 + pair % nkh;
+        const bool ov = o < d.Cout;
+        const int oc = ov ? o : d.Cout - 1;
+        const float *gr = gy + (size_t)b0 * gstep + (size_t)oc * S +
+                          (size_t)((z - kd) * d.OH + (y_ - kh)) * d.OW;
+        size_t wb[CT];
+#pragma unroll
+        for (int t = 0; t < CT; ++t)
+            wb[t] = ((size_t)oc * d.Cin + min(t * 16 + j, d.Cin - 1)) * k3 + (size_t)((kd * d.kH + kh) * d.kW);
+        int kw = 0;
+        if (d.kW >= 4) {
+            f32x4 w4[CT];
+            float gv[NB][4];
+#pragma unroll
+            for (int t = 0; t < CT; ++t) w4[t] = *(const f4u *)(w + wb[t]);
+#pragma unroll
+            for (int n = 0; n < NB; ++n)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int xo = j - u;
+                    const bool in = ov && bv[n] && (unsigned)xo < (unsigned)d.OW;
+                    const float v_ = gr[in ? (size_t)n * gstep + xo : 0];
+                    gv[n][u] = in ? v_ : 0.0f;
+                }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int n = 0; n < NB; ++n)
+#pragma unroll
+                    for (int t = 0; t < CT; ++t) acc[n][t] = mma(w4[t][u], gv[n][u], acc[n][t]);
+            kw = 4;
+        }
+        for (; kw < d.kW; ++kw) {
+            const int xo = j - kw;
+            float wv_[CT], gv[NB];
+#pragma unroll
+            for (int t = 0; t < CT; ++t) wv_[t] = w[wb[t] + kw];
+#pragma unroll
+            for (int n = 0; n < NB; ++n) {
+                const bool in = ov && bv[n] && (unsigned)xo < (unsigned)d.OW;
+                const float v_ = gr[in ? (size_t)n * gstep + xo : 0];
+                gv[n] = in ? v_ : 0.0f;
+            }
+#pragma unroll
+            for (int n = 0; n < NB; ++n)
+#pragma unroll
+                for (int t = 0; t < CT; ++t) acc[n][t] = mma(wv_[t], gv[n], acc[n][t]);
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+        if (n) __syncthreads();                            // part is reused
+        reduce_tiles<CT>(part, acc[n], wave, lane);
+        if (!bv[n]) continue;                              // uniform
+        for (int idx = tid; idx < CT * 256; idx += NW * 64) {
+            const int t = idx >> 8, l = (idx >> 2) & 63, r = idx & 3;
+            const int c = t * 16 + 4 * (l >> 4) + r, x_ = l & 15;
+            if (c >= d.Cin || x_ >= d.W) continue;
+            float v = 0.0f;
+#pragma unroll
+            for (int wv = 0; wv < NW; ++wv) v += part[((wv * CT + t) * 64 + l) * 4 + r];
+            gx[((size_t)(b0 + n) * d.Cin + c) * V + (size_t)(z * d.H + y_) * d.W + x_] = v;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------ backward data, wide
 // Same decomposition as conv3d_fwd_wide_kernel for the input gradient of large tensors.
 template <int CT>
@@ -2019,6 +2125,32 @@ wb_vol_fn wb_vol_kernel(int otiles, int ktw)
 #undef WBV_K
 }
 
+// Resident workgroups per CU of a kernel with `lds` bytes of dynamic LDS: asked once per (device,
+// kernel, bytes) and kept -- the query is a host call of microseconds and not legal under stream
+// capture.  Also raises the kernel's dynamic-LDS limit when it needs more than 64 KB.  0: failed.
+int occupancy_cached(const void *fn, size_t lds)
+{
+    struct Slot { const void *fn; size_t lds; int occ; };
+    static std::mutex mu;
+    static Slot slots[64][24] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    std::lock_guard<std::mutex> lock(mu);
+    Slot *slot = nullptr;
+    for (Slot &c : slots[dev]) {
+        if (c.fn == fn && c.lds == lds) return c.occ;
+        if (!c.fn && !slot) slot = &c;
+    }
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return 0;
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, BLOCK, lds) != hipSuccess || occ <= 0)
+        return 0;
+    if (slot) { slot->fn = fn; slot->lds = lds; slot->occ = occ; }
+    return occ;
+}
+
 // The LDS-staged row kernel: grid (a multiple of 8, one float64 slab per workgroup), LDS bytes and
 // kernel for a shape, or false when the shape takes another path.
 typedef void (*wb_rows_fn)(const float *, const float *, double *, Dims3, int, int);
@@ -2052,12 +2184,8 @@ bool wb_rows_plan(int B, int Cin, int D, int H, int W, int Cout, int kD, int kH,
     const size_t bytes = wbr_lds_bytes(Cin * kD, kH, otiles == 3 ? 4 : otiles);
     if (bytes > RESIDENT_LDS || Cin * kD * 18 > BLOCK * WBR_MAXS) return false;
     const void *kfn = (const void *)wb_rows_kernel(otiles, (ktiles + WAVES - 1) / WAVES);
-    if (bytes > 64 * 1024 &&
-        hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
-        return false;
-    int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, BLOCK, bytes) != hipSuccess || occ <= 0)
-        return false;
+    const int occ = occupancy_cached(kfn, bytes);
+    if (occ <= 0) return false;
     *grid = wm_num_cus() * occ & ~7;
     *lds = bytes;
     return *grid > 0;
@@ -2106,31 +2234,8 @@ bool wb_staged_plan(int B, int Cin, int D, int H, int W, int Cout, int kD, int k
     const size_t bytes = wbs_lds_bytes(CD, kH, otiles, best_ktw);
     // B addresses are 16-bit words of the ring
     if (bytes > 80 * 1024 || (kH + 1) * wbr_slot_stride(CD) >= (1 << 16)) return false;
-    // one occupancy query per (device, kernel, LDS bytes): a host call of microseconds, and not
-    // legal under stream capture
-    struct Slot { const void *fn; size_t lds; int occ; };
-    static std::mutex mu;
-    static Slot slots[64][8] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
-    int occ = 0;
-    {
-        std::lock_guard<std::mutex> lock(mu);
-        Slot *slot = nullptr;
-        for (Slot &c : slots[dev]) {
-            if (c.fn == (const void *)best && c.lds == bytes) { occ = c.occ; break; }
-            if (!c.fn && !slot) slot = &c;
-        }
-        if (!occ) {
-            if (bytes > 64 * 1024 &&
-                hipFuncSetAttribute((const void *)best, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)bytes) != hipSuccess)
-                return false;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, best, BLOCK, bytes) != hipSuccess || occ <= 0)
-                return false;
-            if (slot) { slot->fn = (const void *)best; slot->lds = bytes; slot->occ = occ; }
-        }
-    }
+    int occ = occupancy_cached((const void *)best, bytes);
+    if (occ <= 0) return false;
 #ifdef WM_PROBE_ENV
     if (const char *e = getenv("WM_WB_BPC")) occ = min(occ, atoi(e));
 #endif
@@ -2187,8 +2292,7 @@ extern "C" int wm_conv3d_fwd_f32(const float *x, const float *w, const float *b,
             const void *kfn = otk == 1   ? (const void *)conv3d_fwd_rows_kernel<1>
                               : otk == 2 ? (const void *)conv3d_fwd_rows_kernel<2>
                                          : (const void *)conv3d_fwd_rows_kernel<4>;
-            int occ = 0;
-            WM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, BLOCK, lds));
+            const int occ = occupancy_cached(kfn, lds);
             WM_REQUIRE(occ > 0, WM_ERR_HIP, "conv3d_fwd_rows_kernel does not fit on a CU");
             const int units = B * d.OD * d.OH * ((d.OW + ROWS_SEG - 1) / ROWS_SEG);
             int grid = wm_num_cus() * occ & ~7;
@@ -2313,8 +2417,7 @@ static int conv3d_bwd_data_impl(const float *gy, const float *w, float *gx, cons
             const void *kfn = ctk == 1   ? (const void *)conv3d_bwd_data_rows_kernel<1>
                               : ctk == 2 ? (const void *)conv3d_bwd_data_rows_kernel<2>
                                          : (const void *)conv3d_bwd_data_rows_kernel<4>;
-            int occ = 0;
-            WM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, BLOCK, lds));
+            const int occ = occupancy_cached(kfn, lds);
             WM_REQUIRE(occ > 0, WM_ERR_HIP, "conv3d_bwd_data_rows_kernel does not fit on a CU");
             const int units = B * D * H * ((W + ROWS_SEG - 1) / ROWS_SEG);
             int grid = wm_num_cus() * occ & ~7;
@@ -2341,6 +2444,24 @@ static int conv3d_bwd_data_impl(const float *gy, const float *w, float *gx, cons
             hipLaunchKernelGGL(conv3d_bwd_data_wide_kernel<4>, dim3(wblocks), dim3(BLOCK), 0, st, gy,
                                w, gx, d, K2, Mtot);
         WM_BWD_DATA_DONE("conv3d_bwd_data_wide_kernel");
+    }
+    // rows of at most 16 positions whose taps are mostly out of range: one workgroup per row
+    if (W <= 16 && 2 * d.OD * d.OH <= D * H && (long long)B * D * H <= 0x7fffffffll) {
+        // two batch items per workgroup while that still leaves a workgroup per CU
+        const bool two = (long long)((B + 1) / 2) * D * H >= wm_num_cus();
+        const int rows = (two ? (B + 1) / 2 : B) * D * H;
+#define WM_ROWTAP(CT_)                                                                           \
+    if (two)                                                                                     \
+        hipLaunchKernelGGL((conv3d_bwd_data_rowtap_kernel<CT_, 8, 2>), dim3(rows), dim3(512), 0, st, \
+                           gy, w, gx, d);                                                        \
+    else                                                                                         \
+        hipLaunchKernelGGL((conv3d_bwd_data_rowtap_kernel<CT_, 8, 1>), dim3(rows), dim3(512), 0, st, \
+                           gy, w, gx, d)
+        if (ct == 1) { WM_ROWTAP(1); }
+        else if (ct == 2) { WM_ROWTAP(2); }
+        else { WM_ROWTAP(4); }
+#undef WM_ROWTAP
+        WM_BWD_DATA_DONE("conv3d_bwd_data_rowtap_kernel");
     }
     const int blocks = (Mtot + 15) / 16;            // one workgroup per 16-position tile
     const bool deep = blocks <= 4 * wm_num_cus();
