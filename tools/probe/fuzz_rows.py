@@ -33,6 +33,9 @@ for it in range(cases):
     if OW < 64:
         continue
     OH = int(np.ceil(1.06e6 / (B * OD * OW))); H = OH + kH - 1
+    if len(sys.argv) > 3 and sys.argv[3] == "short":      # stripes of a few rows: a top every few units
+        OH = int(rng.integers(1, 6)); H = OH + kH - 1
+        B = int(np.ceil(1.06e6 / (OD * OH * OW)))
     flops = 2.0 * B * OD * OH * OW * Cout * K
     if flops > 12e9 or B * Cin * D * H * W > 3e7:
         continue
