@@ -731,7 +731,7 @@ def conv_stack_cpu_library(ws, bs, x1, g1, relu, reps=5):
 def run_conv32(steps, warmup, rank, world, cpu_base, N=8, C=32, H=721, W=1440):
     """BASELINE configs[3] read literally (4b): one Conv(32->32, 3x3) layer on (N,32,721,1440),
     forward + backward(data, weight, bias) -- the implicit-GEMM MFMA kernels."""
-    from weather_model_amd import ops, dp
+    from weather_model_amd import ops, dp, _lib
     x = ops.synth_uniform((N, C, H, W), seed=30, offset=rank * N * C * H * W)
     w = ops.synth_uniform((C, C, 3, 3), seed=31, lo=-1.0 / 17, hi=1.0 / 17)
     b = ops.synth_uniform((C,), seed=32, lo=-1.0 / 17, hi=1.0 / 17)
@@ -762,6 +762,17 @@ def run_conv32(steps, warmup, rank, world, cpu_base, N=8, C=32, H=721, W=1440):
 
     total = timed_steps(step, steps, warmup, world)
     ms = {k: float(np.mean([a.elapsed_time(c) for a, c in v])) for k, v in evs.items()}
+    # the clock the chip held under the weight-gradient kernel's MFMA load (the kernel's first
+    # workgroup leaves its cycle and wall-clock counts behind the partial sums)
+    clock_mhz = None
+    wsb = ops.conv2d_bwd_wb_workspace(x.shape, w.shape)
+    off = _lib.lib().wm_conv3d_bwd_wb_clock_offset(N, C, 1, H, W, C, 1, 3, 3)
+    if off:
+        for _ in range(3):
+            ops.conv2d_backward_wb(x, gy, w.shape, ws=wsb)
+        rec = wsb[off:off + 24].cpu().numpy().view(np.uint64)
+        if int(rec[0]) == 0x574d434c4f434b31 and rec[2] > 0:
+            clock_mhz = float(rec[1]) / float(rec[2]) * 100.0
     pts = N * H * W
     flops_pass = 2.0 * C * C * 9 * N * (H - 2) * (W - 2)
     ach = 3 * flops_pass / (sum(ms.values()) * 1e-3) / 1e12
@@ -782,7 +793,8 @@ def run_conv32(steps, warmup, rank, world, cpu_base, N=8, C=32, H=721, W=1440):
                          "kernel": "conv3d_fwd_rows_kernel + conv3d_bwd_data_rows_kernel + "
                                    "conv3d_bwd_wb_staged_kernel",
                          "algorithmic_flops_per_point_per_pass": 2 * C * C * 9,
-                         "TFLOPs": {k: flops_pass / (v * 1e-3) / 1e12 for k, v in ms.items()}}}
+                         "TFLOPs": {k: flops_pass / (v * 1e-3) / 1e12 for k, v in ms.items()},
+                         "shader_clock_mhz_under_bwd_wb": clock_mhz}}
 
 
 def run_conv32x3(steps, warmup, rank, world, cpu_base, N=8, C=32, H=721, W=1440, L=3):

@@ -120,6 +120,13 @@ int wm_conv3d_bwd_wb_f32(const float *x, const float *gy, float *gw, float *gb,
                          void *workspace, size_t workspace_bytes,
                          int B, int Cin, int D, int H, int W, int Cout, int kD, int kH, int kW,
                          void *stream);
+/* Measurement aid, no counterpart in the reference: byte offset inside the workspace at which
+ * wm_conv3d_bwd_wb_f32 leaves three uint64 for this shape -- a magic word ("WMCLOCK1"), the shader
+ * cycles and the 100 MHz wall-clock ticks its first workgroup ran for (cycles / ticks * 100 = the
+ * clock in MHz the chip held under the kernel's MFMA load) -- or 0 when the shape's kernel leaves
+ * none.  bench.py prints the figure beside the MFMA roofline. */
+size_t wm_conv3d_bwd_wb_clock_offset(int B, int Cin, int D, int H, int W, int Cout,
+                                     int kD, int kH, int kW);
 
 /* Replaces keras.layers.MaxPool3D(pool_size=2, strides=2) (convolution.py:165,167,171,173) and its
  * gradient.  x is (B,A1,A2,A3,C) contiguous and the window runs over A1,A2,A3 ("channels_last",

@@ -28,6 +28,7 @@ SIGNATURES = {
     "wm_conv3d_fwd_f32": (c_int, [vp, vp, vp, vp] + [c_int] * 9 + [c_int, vp]),
     "wm_conv3d_bwd_data_f32": (c_int, [vp, vp, vp] + [c_int] * 9 + [vp]),
     "wm_conv3d_bwd_wb_workspace_bytes": (c_sz, [c_int] * 9),
+    "wm_conv3d_bwd_wb_clock_offset": (c_sz, [c_int] * 9),
     "wm_conv3d_bwd_wb_f32": (c_int, [vp, vp, vp, vp, vp, c_sz] + [c_int] * 9 + [vp]),
     "wm_maxpool3d_fwd_f32": (c_int, [vp, vp, vp] + [c_int] * 5 + [vp]),
     "wm_maxpool3d_bwd_f32": (c_int, [vp, vp, vp] + [c_int] * 5 + [vp]),

@@ -1539,6 +1539,7 @@ __global__ __launch_bounds__(BLOCK) void conv3d_bwd_wb_rows_kernel(const float *
 // Sums are float64 in registers (OTW * KTW <= 10), written once to the workgroup's slab.
 typedef float f32x4a4 __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr unsigned long long WBS_CLOCK_MAGIC = 0x574d434c4f434b31ull;   // "WMCLOCK1"
 constexpr int WBS_NX = 3;          // staged 16-byte pieces per thread: an x row set, Cin*kD*17 <= 768
 constexpr int WBS_NG = 2;          // the gy tile, 32 channels x 16 pieces
 
@@ -1676,6 +1677,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         }
     };
 
+    // workgroup 0 leaves its shader-cycle and 100 MHz wall-clock counts behind the slabs: their
+    // ratio is the clock the chip ran this kernel at (bench.py prints it beside the roofline)
+    const unsigned long long clk0 = __builtin_readcyclecounter(), wall0 = wall_clock64();
     double dsum[KTW][OTW][4];
 #pragma unroll
     for (int q = 0; q < KTW; ++q)
@@ -1861,6 +1865,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                 const int o = (og * OTW + t) * 16 + 4 * g + r;
                 if (k < K && o < d.Cout) slab[(size_t)o * (K + 1) + k] = dsum[q][t][r];
             }
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        unsigned long long *rec = (unsigned long long *)(partial + (size_t)gridDim.x * d.Cout * (K + 1));
+        rec[0] = WBS_CLOCK_MAGIC;
+        rec[1] = __builtin_readcyclecounter() - clk0;
+        rec[2] = wall_clock64() - wall0;
     }
     // a channel's 16 pieces sit in 16 consecutive lanes
 #pragma unroll
@@ -2506,13 +2516,25 @@ extern "C" size_t wm_conv3d_bwd_wb_workspace_bytes(int B, int Cin, int D, int H,
     int rgrid = 0;
     size_t rlds = 0;
     WbStagedPlan sp;
-    if (wb_staged_plan(B, Cin, D, H, W, Cout, kD, kH, kW, &sp)) rgrid = sp.grid, splits = (size_t)sp.grid;
-    else if (wb_rows_plan(B, Cin, D, H, W, Cout, kD, kH, kW, &rgrid, &rlds)) splits = (size_t)rgrid;
+    if (wb_staged_plan(B, Cin, D, H, W, Cout, kD, kH, kW, &sp))      // slabs + the clock record
+        return wm_align_up((size_t)sp.grid * nent * sizeof(double) + 3 * sizeof(unsigned long long), 256);
+    if (wb_rows_plan(B, Cin, D, H, W, Cout, kD, kH, kW, &rgrid, &rlds)) splits = (size_t)rgrid;
     int vktw = 0, vgroups = 0;
     size_t vlds = 0;
     if (!rgrid && wb_vol_plan(B, Cin, D, H, W, Cout, kD, kH, kW, &vktw, &vgroups, &vlds))
         splits = (size_t)B * (D - kD + 1);                          // one slab per output plane
     return wm_align_up(splits * nent * sizeof(double), 256);
+}
+
+extern "C" size_t wm_conv3d_bwd_wb_clock_offset(int B, int Cin, int D, int H, int W, int Cout,
+                                                int kD, int kH, int kW)
+{
+    if (B <= 0 || Cin <= 0 || D <= 0 || H <= 0 || W <= 0 || Cout <= 0 || kD <= 0 || kH <= 0 ||
+        kW <= 0 || kD > D || kH > H || kW > W)
+        return 0;
+    WbStagedPlan sp;
+    if (!wb_staged_plan(B, Cin, D, H, W, Cout, kD, kH, kW, &sp)) return 0;
+    return (size_t)sp.grid * ((size_t)Cout * Cin * kD * kH * kW + Cout) * sizeof(double);
 }
 
 extern "C" int wm_conv3d_bwd_wb_f32(const float *x, const float *gy, float *gw, float *gb,
