@@ -1,9 +1,10 @@
-"""One-off fuzz of the large-grid (row) conv kernels against the C oracle: random shapes inside the
-staged weight-gradient plan (>= 1.05 M outputs, <= 32 output channels, Cin*kD <= 45), forward,
-backward-data and weight/bias gradient.  python tools/probe/fuzz_rows.py [cases] [seed]"""
+"""Fuzz of the large-grid (row) conv kernels against the C oracle (test infrastructure; not
+collected by pytest -- run by name on a GPU box): random shapes inside the staged weight-gradient
+plan (>= 1.05 M outputs, <= 32 output channels, Cin*kD <= 45), forward, backward-data and
+weight/bias gradient.  python tests/fuzz_rows.py [cases] [seed] [short]"""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
