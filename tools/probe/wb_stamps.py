@@ -2,8 +2,8 @@
 cycle/wall-clock stamps each workgroup leaves in a debug build:
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DWM_WB_STAMPS -DWM_PROBE_ENV -Iinclude \
         -Iweather_model_amd/csrc weather_model_amd/csrc/*.hip -o tools/probe/variants/libwm_wbs.so
-WM_WB_BPC=1 caps the launch at one workgroup per CU; -DWM_NO_STAGED in the build gives the round-1
-row kernel (its stamps then split a unit into fill and MFMA steps)."""
+WM_WB_BPC=1 caps the launch at one workgroup per CU.  (The fill / MFMA-step split quoted in DESIGN.md
+came from the same stamps placed around the two barriers of the round-1 row kernel.)"""
 import ctypes, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -40,15 +40,13 @@ print("shader clock MHz (cycles / 100 MHz wall clock): mean %.0f min %.0f max %.
 print("wall us per workgroup: mean %.1f min %.1f max %.1f" % (wall.mean(), wall.min(), wall.max()))
 per_wg = (a[:, 3] / units).mean()
 print("cycles per unit and workgroup: %.0f   (top-of-stripe fills: %.0f of them)" % (per_wg, (a[:, 0] / units).mean()))
-if a[:, 1].sum() > 0:                       # the round-1 row kernel's split
-    print("  between the barriers %.0f, MFMA steps %.0f clk/unit" % ((a[:, 0] / units).mean(), (a[:, 1] / units).mean()))
 idx = np.flatnonzero(keep)
 key = (idx & 7) * 4096 + ((hw >> 13) & 7) * 512 + ((hw >> 12) & 1) * 256 + ((hw >> 8) & 15)
 per_cu = {}
 for i, k in enumerate(key):
     per_cu.setdefault(int(k), []).append(i)
 bpc = np.mean([len(v) for v in per_cu.values()])
-mf = 9 * 16 * 32 if "old" not in os.environ.get("WB_LIB", "") else 10 * 16 * 32
+mf = 9 * 16 * 32
 print("workgroups per CU %.2f; MFMA issue floor %d clk per unit and wave -> pipe busy %.1f %% while all are resident" % (
     bpc, mf, 100.0 * mf * bpc / per_wg))
 if bpc > 1.5:

@@ -1258,13 +1258,6 @@ __host__ __device__ inline size_t wbr_lds_bytes(int cd, int kH, int ot)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src),    \
                                      (__attribute__((address_space(3))) void *)(dst), 16, 0, 0)
 
-#ifdef WM_WB_STAMPS
-// debug build only (tools/probe/wb_stamps.py): per workgroup, shader-clock cycles spent between
-// the two barriers of a unit (fill) and in the MFMA steps, and the wall/shader clocks at both ends
-__device__ unsigned long long wm_wb_stamps[1024 * 8 + 1024];
-#define WB_CLK() __builtin_readcyclecounter()
-#endif
-
 template <int OT, int KTW>
 __global__ __launch_bounds__(BLOCK) void conv3d_bwd_wb_rows_kernel(const float *__restrict__ x,
                                                                    const float *__restrict__ gy,
@@ -1347,10 +1340,6 @@ __global__ __launch_bounds__(BLOCK) void conv3d_bwd_wb_rows_kernel(const float *
     // workgroups per CU then, but no read-modify-write traffic: 32 -> 32 channels 3x3 1.87 ->
     // 1.77 ms), else in the slab
     constexpr bool REGSUM = wbr_regsum(OT, KTW);
-#ifdef WM_WB_STAMPS
-    unsigned long long t_fill = 0, t_comp = 0, t_flush = 0;
-    const unsigned long long c_begin = WB_CLK(), w_begin = wall_clock64();
-#endif
     double dsum[REGSUM ? KTW : 1][REGSUM ? OT : 1][4];
     if constexpr (REGSUM) {
 #pragma unroll
@@ -1391,9 +1380,6 @@ __global__ __launch_bounds__(BLOCK) void conv3d_bwd_wb_rows_kernel(const float *
         const int xs0 = min(ow0, d.W - WBR_XW), delta = ow0 - xs0;
         const float *xsrc = x + (size_t)b_ * xsample + (size_t)((od * d.H + oh) * d.W + xs0);
         const float *gsrc = gy + (size_t)b_ * gsample + (size_t)((od * d.OH + oh) * d.OW + ow0);
-#ifdef WM_WB_STAMPS
-        const unsigned long long c0 = WB_CLK();
-#endif
         __syncthreads();                                   // every wave is past its reads of the tile
         // input rows oh .. oh+kH-1: all of them at the top of a run or stripe, else the last
         for (int kh = (unit == ufirst || oh == 0) ? 0 : d.kH - 1; kh < d.kH; ++kh) {
@@ -1428,10 +1414,6 @@ __global__ __launch_bounds__(BLOCK) void conv3d_bwd_wb_rows_kernel(const float *
 #define WBR_MMA(a_, b_)                                                                      \
     _Pragma("unroll") for (int q = 0; q < KTW; ++q)                                          \
         _Pragma("unroll") for (int t = 0; t < OT; ++t) acc[q][t] = mma(a_[t], b_[q], acc[q][t]);
-#ifdef WM_WB_STAMPS
-        const unsigned long long c1 = WB_CLK();
-        t_fill += c1 - c0;
-#endif
         float a0[OT], b0[KTW], a1[OT], b1[KTW];
         int kofd[KTW];
 #pragma unroll
@@ -1454,13 +1436,7 @@ __global__ __launch_bounds__(BLOCK) void conv3d_bwd_wb_rows_kernel(const float *
         }
 #undef WBR_OPS
 #undef WBR_MMA
-#ifdef WM_WB_STAMPS
-        t_comp += WB_CLK() - c1;
-#endif
     }
-#ifdef WM_WB_STAMPS
-    const unsigned long long c2 = WB_CLK();
-#endif
     if constexpr (!REGSUM) {
     // WBR_FLUSH units (1024 outputs) of fp32 accumulation go to the float64 slab
 #pragma unroll
@@ -1488,18 +1464,7 @@ __global__ __launch_bounds__(BLOCK) void conv3d_bwd_wb_rows_kernel(const float *
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dsum[q][t][r] += (double)acc[q][t][r];
     }
-#ifdef WM_WB_STAMPS
-    t_flush += WB_CLK() - c2;
-#endif
     }
-#ifdef WM_WB_STAMPS
-    if ((tid & 63) == 0 && blockIdx.x < 1024 && wave < 1) {
-        unsigned long long *o = wm_wb_stamps + 8 * blockIdx.x;
-        o[0] = t_fill; o[1] = t_comp; o[2] = t_flush; o[3] = WB_CLK() - c_begin;
-        o[4] = wall_clock64() - w_begin; o[5] = w_begin; o[6] = uend - ufirst;
-        o[7] = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (8 << 6) | 4) /* HW_ID: cu id */;
-    }
-#endif
     if constexpr (REGSUM) {
 #pragma unroll
         for (int q = 0; q < KTW; ++q) {
@@ -1537,6 +1502,13 @@ __global__ __launch_bounds__(BLOCK) void conv3d_bwd_wb_rows_kernel(const float *
 //    (32 -> 32, 3x3: 2 x 2, nine tap tiles and one channel tile per wave: 9 MFMAs per step and
 //    no empty tile, where 1 x 4 ran 10 with two of 20 tiles idle).
 // Sums are float64 in registers (OTW * KTW <= 10), written once to the workgroup's slab.
+#ifdef WM_WB_STAMPS
+// debug build only (tools/probe/wb_stamps.py): per workgroup, the shader cycles spent in
+// top-of-stripe fills, and the wall / shader clocks at both ends
+__device__ unsigned long long wm_wb_stamps[1024 * 8 + 1024];
+#define WB_CLK() __builtin_readcyclecounter()
+#endif
+
 typedef float f32x4a4 __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr unsigned long long WBS_CLOCK_MAGIC = 0x574d434c4f434b31ull;   // "WMCLOCK1"
