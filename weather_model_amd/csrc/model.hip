@@ -117,51 +117,70 @@ __device__ __forceinline__ void put_tile(float *dst, int stride, int row0, int c
 // two 16-row output tiles of a layer as two interleaved MFMA chains (each unit is one dependent
 // chain on a single accumulator and the phases are latency-bound: SQ counters showed the MFMA
 // pipe 41 % busy with the waves waiting 56 % of the time).
+// The MFMA's contraction index is the lane group g, and nothing obliges step t to take input
+// channels in order: step (T, r) takes channel 16 T + 4 g + r -- which is exactly the element
+// acc_T[r] this lane holds of the layer below (an accumulator tile keeps row 4 g + r, column i in
+// lane (i, g)).  So a layer's B operands ARE the previous layer's accumulators, in registers: no
+// LDS write -> read round trip between the layers of a wave's chain (the tiles still go to LDS for
+// the backward pass, but nothing waits for them).  The packed weights follow the same order.
 template <int K>   // K = Cin; Cout = 32
-__device__ __forceinline__ void conv_fwd_col(float *lds, int wp, int hin, int hout, int c0,
-                                             int lane, int i, int g)
+__device__ __forceinline__ void conv_fwd_col(float *lds, int wp, const f32x4 (&hin)[K / 16],
+                                             f32x4 (&hout)[2], int hout_off, int c0, int lane, int i,
+                                             int g)
 {
     constexpr int STEPS = K / 4 + 1;
     const float *a0 = lds + wp + lane, *a1 = a0 + STEPS * 64;
     // rank-1 terms and bias as one MFMA step: A = [b, as, ae, 0], B = [1, s, e, 0]
     const float ee = lds[L_EE + g * NP + c0 + i];         // EE rows 0..3 = 1, s, e, 0
-    const float *hb = lds + hin + (K / 4) * g * NP + c0 + i;
     f32x4 acc0 = mma(a0[0], ee, (f32x4){0.f, 0.f, 0.f, 0.f});
     f32x4 acc1 = mma(a1[0], ee, (f32x4){0.f, 0.f, 0.f, 0.f});
 #pragma unroll
     for (int t = 0; t < K / 4; ++t) {
-        const float b = hb[t * NP];
+        const float b = hin[t >> 2][t & 3];
         acc0 = mma(a0[(t + 1) * 64], b, acc0);
         acc1 = mma(a1[(t + 1) * 64], b, acc1);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) { acc0[r] = fmaxf(acc0[r], 0.0f); acc1[r] = fmaxf(acc1[r], 0.0f); }
-    put_tile(lds + hout, NP, 0, c0, acc0, i, g);
-    put_tile(lds + hout, NP, 16, c0, acc1, i, g);
+    put_tile(lds + hout_off, NP, 0, c0, acc0, i, g);
+    put_tile(lds + hout_off, NP, 16, c0, acc1, i, g);
+    hout[0] = acc0;
+    hout[1] = acc1;
 }
 
 // backward-data of a conv layer for one column tile:
 // dZin[c][n] = relu'(Hin[c][n]) * sum_o Wm[o][c] dZout[o][n];  K = Cin (16 or 32 rows), Cout = 32
+// The contraction over the 32 output channels takes them in the same order (step (T, r) <-> channel
+// 16 T + 4 g + r), so dZout comes from the registers of the layer above as well.
 template <int K>
-__device__ __forceinline__ void conv_bwd_col(float *lds, int wp, int zout, int hin, int zin, int n0,
-                                             int lane, int i, int g)
+__device__ __forceinline__ void conv_bwd_col(float *lds, int wp, const f32x4 (&zout)[2], int hin,
+                                             int zin_off, f32x4 (&zin)[2], int n0, int lane, int i,
+                                             int g)
 {
     const float *a0 = lds + wp + lane, *a1 = a0 + 8 * 64;
-    const float *zb = lds + zout + 8 * g * NP + n0 + i;
+    // relu' mask of the layer below: read ahead of the chain
+    float hm0[4], hm1[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        hm0[r] = lds[hin + (4 * g + r) * NP + n0 + i];
+        hm1[r] = K == 32 ? lds[hin + (16 + 4 * g + r) * NP + n0 + i] : 0.0f;
+    }
     f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-        const float b = zb[t * NP];
+        const float b = zout[t >> 2][t & 3];
         acc0 = mma(a0[t * 64], b, acc0);
         if (K == 32) acc1 = mma(a1[t * 64], b, acc1);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        acc0[r] = lds[hin + (4 * g + r) * NP + n0 + i] > 0.0f ? acc0[r] : 0.0f;
-        if (K == 32) acc1[r] = lds[hin + (16 + 4 * g + r) * NP + n0 + i] > 0.0f ? acc1[r] : 0.0f;
+        acc0[r] = hm0[r] > 0.0f ? acc0[r] : 0.0f;
+        if (K == 32) acc1[r] = hm1[r] > 0.0f ? acc1[r] : 0.0f;
     }
-    put_tile(lds + zin, NP, 0, n0, acc0, i, g);
-    if (K == 32) put_tile(lds + zin, NP, 16, n0, acc1, i, g);
+    put_tile(lds + zin_off, NP, 0, n0, acc0, i, g);
+    if (K == 32) put_tile(lds + zin_off, NP, 16, n0, acc1, i, g);
+    zin[0] = acc0;
+    zin[1] = acc1;
 }
 
 // fill the packed operands of a forward conv layer (see conv_fwd_col)
@@ -177,12 +196,12 @@ __device__ __forceinline__ void pack_conv_fwd(float *lds, int wp, const float *_
         if (step == 0)
             v = g == 0 ? bias[o] : (g == 1 ? lds[aux + o] : (g == 2 ? lds[aux + 32 + o] : 0.0f));
         else
-            v = wmid[(o * K + (step - 1) + (K / 4) * g) * 3 + 1];
+            v = wmid[(o * K + ((step - 1) >> 2) * 16 + 4 * g + ((step - 1) & 3)) * 3 + 1];
         lds[wp + e] = v;
     }
 }
 
-// packed operands of a backward-data conv layer: [c-tile][step t] -> W[o = t + (O/4) g][c]
+// packed operands of a backward-data conv layer: [c-tile][step t] -> W[o = 16 (t/4) + 4 g + t%4][c]
 template <int K, int O>
 __device__ __forceinline__ void pack_conv_bwd(float *lds, int wp, const float *__restrict__ wmid,
                                               int tid)
@@ -190,7 +209,7 @@ __device__ __forceinline__ void pack_conv_bwd(float *lds, int wp, const float *_
     for (int e = tid; e < (K / 16) * (O / 4) * 64; e += THREADS) {
         const int lane = e & 63, q = e >> 6, t = q % (O / 4), ct = q / (O / 4);
         const int i = lane & 15, g = lane >> 4;
-        lds[wp + e] = wmid[((t + (O / 4) * g) * K + ct * 16 + i) * 3 + 1];
+        lds[wp + e] = wmid[(((t >> 2) * 16 + 4 * g + (t & 3)) * K + ct * 16 + i) * 3 + 1];
     }
 }
 
@@ -441,9 +460,10 @@ __global__ __launch_bounds__(THREADS) void model_kernel(
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[r] = fmaxf(acc[r], 0.0f);
             put_tile(lds + L_H1, NP, 0, c0, acc, i, g);
-            conv_fwd_col<16>(lds, W_C2F, L_H1, L_H2, c0, lane, i, g);
-            conv_fwd_col<32>(lds, W_C3F, L_H2, L_H3, c0, lane, i, g);
-            conv_fwd_col<32>(lds, W_C4F, L_H3, L_H4, c0, lane, i, g);
+            f32x4 h1[1] = {acc}, h2[2], h3[2], h4[2];
+            conv_fwd_col<16>(lds, W_C2F, h1, h2, L_H2, c0, lane, i, g);
+            conv_fwd_col<32>(lds, W_C3F, h2, h3, L_H3, c0, lane, i, g);
+            conv_fwd_col<32>(lds, W_C4F, h3, h4, L_H4, c0, lane, i, g);
         }
         lds_barrier();
         STAMP(2);
@@ -547,6 +567,7 @@ __global__ __launch_bounds__(THREADS) void model_kernel(
         // half-unit sums, no mask pass, no barrier (those two phases took 3.7 k cycles of 26 k)
         if (wave < 6) {
             const int n0 = wave * 16;
+            f32x4 z4[2], z3[2], z2[2], z1[2];
             {
                 const float *du = lds + L_DU + 16 * g * SP + i;
                 f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -563,10 +584,12 @@ __global__ __launch_bounds__(THREADS) void model_kernel(
                 }
                 put_tile(lds + L_Z4, NP, 0, n0, acc0, i, g);
                 put_tile(lds + L_Z4, NP, 16, n0, acc1, i, g);
+                z4[0] = acc0;
+                z4[1] = acc1;
             }
-            conv_bwd_col<32>(lds, W_C4B, L_Z4, L_H3, L_Z3, n0, lane, i, g);
-            conv_bwd_col<32>(lds, W_C3B, L_Z3, L_H2, L_Z2, n0, lane, i, g);
-            conv_bwd_col<16>(lds, W_C2B, L_Z2, L_H1, L_Z1, n0, lane, i, g);
+            conv_bwd_col<32>(lds, W_C4B, z4, L_H3, L_Z3, z3, n0, lane, i, g);
+            conv_bwd_col<32>(lds, W_C3B, z3, L_H2, L_Z2, z2, n0, lane, i, g);
+            conv_bwd_col<16>(lds, W_C2B, z2, L_H1, L_Z1, z1, n0, lane, i, g);
         }
         lds_barrier();
         STAMP(10);
