@@ -16,6 +16,7 @@
 #include "common.h"
 #include <cstdlib>
 #include <mutex>
+#include <type_traits>
 
 namespace {
 
@@ -362,19 +363,29 @@ __host__ __device__ inline size_t rows_lds_bytes(int K2, int tiles)
     return steps * tiles * 64 * sizeof(float) + steps * 4 * sizeof(int);
 }
 
+// (NC_: the unit's 16-column chunks, CPW or -- the short last segment of a row -- CPW / 2)
 #define ROWS_LOAD(dst, sbase)                                                          \
     _Pragma("unroll") for (int u = 0; u < UNR; ++u) {                                  \
         const unsigned a_ = lane0 + off[4 * ((sbase) + u) + g];                        \
-        _Pragma("unroll") for (int c = 0; c < CPW; ++c)                                \
+        _Pragma("unroll") for (int c = 0; c < NC_; ++c)                                \
             dst[u][c] = *(const float *)(xb + a_ + 64u * c);                           \
     }
 #define ROWS_MMA(src, sbase)                                                           \
     _Pragma("unroll") for (int u = 0; u < UNR; ++u)                                    \
         _Pragma("unroll") for (int t = 0; t < OT; ++t) {                               \
             const float a = wl[(((sbase) + u) * OT + t) * 64 + lane];                  \
-            _Pragma("unroll") for (int c = 0; c < CPW; ++c)                            \
+            _Pragma("unroll") for (int c = 0; c < NC_; ++c)                            \
                 acc[c][t] = mma(a, src[u][c], acc[c][t]);                              \
         }
+
+// A row's last segment holds OW - 64 (segs - 1) outputs; when that is at most half a unit it is
+// run as a unit of CPW / 2 chunks ending at the row's end instead of a full one shifted left
+// (1438 outputs: 22.5 units of work per row instead of 23).
+__host__ __device__ inline bool rows_short_tail(int width)
+{
+    const int rem = width - (width - 1) / ROWS_SEG * ROWS_SEG;
+    return width >= ROWS_SEG && rem <= ROWS_SEG / 2;
+}
 
 template <int OT>
 __global__ __launch_bounds__(BLOCK) void conv3d_fwd_rows_kernel(const float *__restrict__ x,
@@ -410,6 +421,7 @@ __global__ __launch_bounds__(BLOCK) void conv3d_fwd_rows_kernel(const float *__r
             bv[t][r] = (bias && o < d.Cout) ? bias[o] : 0.0f;
         }
     const int segs = (d.OW + ROWS_SEG - 1) / ROWS_SEG;
+    const bool short_tail = rows_short_tail(d.OW);
     const int units = d.B * d.OD * d.OH * segs;
     const int groups = (units + WAVES - 1) / WAVES;
     const int gpx = (groups + 7) >> 3;
@@ -420,46 +432,51 @@ __global__ __launch_bounds__(BLOCK) void conv3d_fwd_rows_kernel(const float *__r
         const int unit = grp * WAVES + wave;
         if (unit >= units) continue;                       // wave-uniform; no barrier below
         const int row = unit / segs, seg = unit - row * segs;
-        const int ow0 = min(seg * ROWS_SEG, d.OW - ROWS_SEG);
+        const bool half = short_tail && seg == segs - 1;
+        const int ow0 = half ? d.OW - ROWS_SEG / 2 : min(seg * ROWS_SEG, d.OW - ROWS_SEG);
         const int oh = row % d.OH, q = row / d.OH, od = q % d.OD, b_ = q / d.OD;
         const char *xb = (const char *)(x + (size_t)b_ * xsample);
         const unsigned lane0 = 4u * (unsigned)((od * d.H + oh) * d.W + ow0 + j);
-
-        f32x4 acc[CPW][OT];
-#pragma unroll
-        for (int c = 0; c < CPW; ++c)
-#pragma unroll
-            for (int t = 0; t < OT; ++t) acc[c][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        float xa[UNR][CPW], xc[UNR][CPW];
-        ROWS_LOAD(xa, 0)
-        for (int sb = 0; sb < steps; sb += 2 * UNR) {
-            ROWS_LOAD(xc, sb + UNR)
-            __builtin_amdgcn_sched_barrier(0);
-            ROWS_MMA(xa, sb)
-            __builtin_amdgcn_sched_barrier(0);
-            const int nx_ = sb + 2 * UNR < steps ? sb + 2 * UNR : sb;     // last round: unused re-read
-            ROWS_LOAD(xa, nx_)
-            __builtin_amdgcn_sched_barrier(0);
-            ROWS_MMA(xc, sb + UNR)
-            __builtin_amdgcn_sched_barrier(0);
-        }
         char *yb = (char *)(y + (size_t)b_ * ysample);
         const unsigned sp0 = 4u * ((unsigned)((od * d.OH + oh) * d.OW + ow0 + j) + (unsigned)(4 * g) * S);
+        auto run = [&](auto nc_tag) {
+            constexpr int NC_ = decltype(nc_tag)::value;
+            f32x4 acc[CPW][OT];
 #pragma unroll
-        for (int t = 0; t < OT; ++t)
+            for (int c = 0; c < NC_; ++c)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int o = t * 16 + 4 * g + r;
-                if (o < d.Cout) {
-                    const unsigned yo = sp0 + 4u * (unsigned)(t * 16 + r) * S;
+                for (int t = 0; t < OT; ++t) acc[c][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            float xa[UNR][CPW], xc[UNR][CPW];
+            ROWS_LOAD(xa, 0)
+            for (int sb = 0; sb < steps; sb += 2 * UNR) {
+                ROWS_LOAD(xc, sb + UNR)
+                __builtin_amdgcn_sched_barrier(0);
+                ROWS_MMA(xa, sb)
+                __builtin_amdgcn_sched_barrier(0);
+                const int nx_ = sb + 2 * UNR < steps ? sb + 2 * UNR : sb;     // last round: unused re-read
+                ROWS_LOAD(xa, nx_)
+                __builtin_amdgcn_sched_barrier(0);
+                ROWS_MMA(xc, sb + UNR)
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
-                    for (int c = 0; c < CPW; ++c) {
-                        float v = acc[c][t][r] + bv[t][r];
-                        if (relu) v = fmaxf(v, 0.0f);
-                        *(float *)(yb + yo + 64u * c) = v;
+            for (int t = 0; t < OT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = t * 16 + 4 * g + r;
+                    if (o < d.Cout) {
+                        const unsigned yo = sp0 + 4u * (unsigned)(t * 16 + r) * S;
+#pragma unroll
+                        for (int c = 0; c < NC_; ++c) {
+                            float v = acc[c][t][r] + bv[t][r];
+                            if (relu) v = fmaxf(v, 0.0f);
+                            *(float *)(yb + yo + 64u * c) = v;
+                        }
                     }
                 }
-            }
+        };
+        if (half) run(std::integral_constant<int, CPW / 2>{});
+        else run(std::integral_constant<int, CPW>{});
     }
 }
 
@@ -874,12 +891,12 @@ __global__ __launch_bounds__(BLOCK) void conv3d_bwd_data_wide_kernel(const float
         const int k4_ = 4 * ((sbase) + u) + g;                                         \
         const unsigned a_ = lane0 + off[k4_];                                          \
         if (MASKED == 0) {                                                             \
-            _Pragma("unroll") for (int c = 0; c < CPW; ++c)                            \
+            _Pragma("unroll") for (int c = 0; c < NC_; ++c)                            \
                 dst[u][c] = *(const float *)(gb + a_ + 64u * c);                       \
         } else if (MASKED == 1) {       /* rows in range; columns: first and last chunk only */ \
             const int wq_ = w0 + j - (int)(tap[k4_] & 255u);                           \
-            _Pragma("unroll") for (int c = 0; c < CPW; ++c) {                          \
-                if (c == 0 || c == CPW - 1) {                                          \
+            _Pragma("unroll") for (int c = 0; c < NC_; ++c) {                          \
+                if (c == 0 || c == NC_ - 1) {                                          \
                     const bool ok_ = (unsigned)(wq_ + 16 * c) < (unsigned)d.OW;        \
                     const float v_ = *(const float *)(gb + (ok_ ? a_ + 64u * c : 0u)); \
                     dst[u][c] = ok_ ? v_ : 0.0f;                                       \
@@ -892,7 +909,7 @@ __global__ __launch_bounds__(BLOCK) void conv3d_bwd_data_wide_kernel(const float
             const bool rv_ = (unsigned)(dz - (int)(tp_ >> 16)) < (unsigned)d.OD &&     \
                              (unsigned)(h - (int)((tp_ >> 8) & 255u)) < (unsigned)d.OH; \
             const int wq_ = w0 + j - (int)(tp_ & 255u);                                \
-            _Pragma("unroll") for (int c = 0; c < CPW; ++c) {                          \
+            _Pragma("unroll") for (int c = 0; c < NC_; ++c) {                          \
                 const bool ok_ = rv_ && (unsigned)(wq_ + 16 * c) < (unsigned)d.OW;     \
                 const float v_ = *(const float *)(gb + (ok_ ? a_ + 64u * c : 0u));     \
                 dst[u][c] = ok_ ? v_ : 0.0f;                                           \
@@ -900,7 +917,7 @@ __global__ __launch_bounds__(BLOCK) void conv3d_bwd_data_wide_kernel(const float
         }                                                                              \
     }
 
-template <int CT, int MASKED>
+template <int CT, int MASKED, int NC_>
 __device__ __forceinline__ void bwd_rows_unit(const char *gb, const float *wl, const unsigned *off,
                                               const unsigned *tap, const Dims3 &d, int steps,
                                               unsigned lane0, int dz, int h, int w0, int lane,
@@ -962,6 +979,7 @@ __global__ __launch_bounds__(BLOCK) void conv3d_bwd_data_rows_kernel(const float
     __syncthreads();
 
     const int segs = (d.W + ROWS_SEG - 1) / ROWS_SEG;
+    const bool short_tail = rows_short_tail(d.W);
     const int units = d.B * d.D * d.H * segs;
     const int groups = (units + WAVES - 1) / WAVES;
     const int gpx = (groups + 7) >> 3;
@@ -972,34 +990,52 @@ __global__ __launch_bounds__(BLOCK) void conv3d_bwd_data_rows_kernel(const float
         const int unit = grp * WAVES + wave;
         if (unit >= units) continue;                       // wave-uniform; no barrier below
         const int row = unit / segs, seg = unit - row * segs;
-        const int w0 = min(seg * ROWS_SEG, d.W - ROWS_SEG);
+        const bool half = short_tail && seg == segs - 1;
+        const int w0 = half ? d.W - ROWS_SEG / 2 : min(seg * ROWS_SEG, d.W - ROWS_SEG);
         const int h = row % d.H, q = row / d.H, dz = q % d.D, b_ = q / d.D;
         const char *gb = (const char *)(gy + (size_t)b_ * gysample);
         const unsigned lane0 = 4u * (unsigned)((dz * d.OH + h) * d.OW + w0 + j);   // wraps with off[]
-
-        f32x4 acc[CPW][CT];
-#pragma unroll
-        for (int c = 0; c < CPW; ++c)
-#pragma unroll
-            for (int t = 0; t < CT; ++t) acc[c][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        char *xb = (char *)(gx + (size_t)b_ * gxsample);
+        const unsigned sp0 = 4u * ((unsigned)((dz * d.H + h) * d.W + w0 + j) + (unsigned)(4 * g) * V);
         // the first and last segment of a row (2 of 23 units at 1440 columns) leave the row only in
         // their first and last 16 columns as long as kW <= 17: one compare and two selects per tap
         // for those chunks instead of the full range test for all four
         const bool rows_in = dz >= d.kD - 1 && dz < d.OD && h >= d.kH - 1 && h < d.OH;
-        const bool cols_in = w0 >= d.kW - 1 && w0 + ROWS_SEG <= d.OW;
-        if (rows_in && cols_in)
-            bwd_rows_unit<CT, 0>(gb, wl, off, tap, d, steps, lane0, dz, h, w0, lane, acc);
-        else if (rows_in && d.kW <= 17 && CPW >= 2)
-            bwd_rows_unit<CT, 1>(gb, wl, off, tap, d, steps, lane0, dz, h, w0, lane, acc);
-        else
-            bwd_rows_unit<CT, 2>(gb, wl, off, tap, d, steps, lane0, dz, h, w0, lane, acc);
-
-        char *xb = (char *)(gx + (size_t)b_ * gxsample);
-        const unsigned sp0 = 4u * ((unsigned)((dz * d.H + h) * d.W + w0 + j) + (unsigned)(4 * g) * V);
-        if (mask) {
-            // ReLU backward of the layer BELOW fused into this store: mask is that layer's output
-            // (same shape as gx), and its input gradient is gx where the output was positive
-            const char *mb = (const char *)(mask + (size_t)b_ * gxsample);
+        auto run = [&](auto nc_tag) {
+            constexpr int NC_ = decltype(nc_tag)::value;
+            f32x4 acc[CPW][CT];
+#pragma unroll
+            for (int c = 0; c < NC_; ++c)
+#pragma unroll
+                for (int t = 0; t < CT; ++t) acc[c][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const bool cols_in = w0 >= d.kW - 1 && w0 + 16 * NC_ <= d.OW;
+            if (rows_in && cols_in)
+                bwd_rows_unit<CT, 0, NC_>(gb, wl, off, tap, d, steps, lane0, dz, h, w0, lane, acc);
+            else if (rows_in && d.kW <= 17 && NC_ >= 2)
+                bwd_rows_unit<CT, 1, NC_>(gb, wl, off, tap, d, steps, lane0, dz, h, w0, lane, acc);
+            else
+                bwd_rows_unit<CT, 2, NC_>(gb, wl, off, tap, d, steps, lane0, dz, h, w0, lane, acc);
+            if (mask) {
+                // ReLU backward of the layer BELOW fused into this store: mask is that layer's
+                // output (same shape as gx), and its input gradient is gx where that was positive
+                const char *mb = (const char *)(mask + (size_t)b_ * gxsample);
+#pragma unroll
+                for (int t = 0; t < CT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int ch = t * 16 + 4 * g + r;
+                        if (ch < d.Cin) {
+                            const unsigned xo = sp0 + 4u * (unsigned)(t * 16 + r) * V;
+                            float mv[CPW];
+#pragma unroll
+                            for (int c = 0; c < NC_; ++c) mv[c] = *(const float *)(mb + xo + 64u * c);
+#pragma unroll
+                            for (int c = 0; c < NC_; ++c)
+                                *(float *)(xb + xo + 64u * c) = mv[c] > 0.0f ? acc[c][t][r] : 0.0f;
+                        }
+                    }
+                return;
+            }
 #pragma unroll
             for (int t = 0; t < CT; ++t)
 #pragma unroll
@@ -1007,27 +1043,13 @@ __global__ __launch_bounds__(BLOCK) void conv3d_bwd_data_rows_kernel(const float
                     const int ch = t * 16 + 4 * g + r;
                     if (ch < d.Cin) {
                         const unsigned xo = sp0 + 4u * (unsigned)(t * 16 + r) * V;
-                        float mv[CPW];
 #pragma unroll
-                        for (int c = 0; c < CPW; ++c) mv[c] = *(const float *)(mb + xo + 64u * c);
-#pragma unroll
-                        for (int c = 0; c < CPW; ++c)
-                            *(float *)(xb + xo + 64u * c) = mv[c] > 0.0f ? acc[c][t][r] : 0.0f;
+                        for (int c = 0; c < NC_; ++c) *(float *)(xb + xo + 64u * c) = acc[c][t][r];
                     }
                 }
-            continue;
-        }
-#pragma unroll
-        for (int t = 0; t < CT; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ch = t * 16 + 4 * g + r;
-                if (ch < d.Cin) {
-                    const unsigned xo = sp0 + 4u * (unsigned)(t * 16 + r) * V;
-#pragma unroll
-                    for (int c = 0; c < CPW; ++c) *(float *)(xb + xo + 64u * c) = acc[c][t][r];
-                }
-            }
+        };
+        if (half) run(std::integral_constant<int, CPW / 2>{});
+        else run(std::integral_constant<int, CPW>{});
     }
 }
 
