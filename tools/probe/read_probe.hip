@@ -1,0 +1,74 @@
+// Read-only streaming variants: can anything beat the 5.97 TB/s of a plain grid-stride dwordx4 read?
+// hipcc --offload-arch=gfx950 -O3 -o tools/probe/read_probe tools/probe/read_probe.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#pragma clang diagnostic ignored "-Wunused-value"
+#pragma clang diagnostic ignored "-Wunused-result"
+#include <vector>
+typedef float f4 __attribute__((ext_vector_type(4)));
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void rd(const f4* __restrict__ in, float* __restrict__ out, long long n4) {
+    f4 s = {0, 0, 0, 0};
+    const long long stride = (long long)gridDim.x * 256;
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    for (; i + (U - 1) * stride < n4; i += U * stride) {
+        f4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = NT ? __builtin_nontemporal_load(in + i + u * stride) : in[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < U; ++u) s += v[u];
+    }
+    for (; i < n4; i += stride) s += in[i];
+    if (s.x + s.y + s.z + s.w == 12345.678f) out[0] = s.x;
+}
+// each wave owns a contiguous range and reads U KiB-chunks per iteration
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void rdc(const f4* __restrict__ in, float* __restrict__ out, long long n4) {
+    const long long nw = (long long)gridDim.x * 4, w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long t0 = (n4 / 64) * w / nw, t1 = (n4 / 64) * (w + 1) / nw;
+    const int lane = threadIdx.x & 63;
+    f4 s = {0, 0, 0, 0};
+    long long t = t0;
+    for (; t + U <= t1; t += U) {
+        f4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = NT ? __builtin_nontemporal_load(in + (t + u) * 64 + lane) : in[(t + u) * 64 + lane];
+#pragma unroll
+        for (int u = 0; u < U; ++u) s += v[u];
+    }
+    for (; t < t1; ++t) s += in[t * 64 + lane];
+    if (s.x + s.y + s.z + s.w == 12345.678f) out[0] = s.x;
+}
+__global__ void fill(float* x, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        unsigned h = (unsigned)i * 2654435761u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        x[i] = (float)(h >> 8) * (1.0f / 16777216.0f);
+    }
+}
+int main() {
+    const long long n = 1700000000ll;          // 6.8 GB, the gram16 working set
+    const int NB = 1;
+    float *x, *y;
+    hipMalloc(&x, n * 4); hipMalloc(&y, 1024);
+    hipLaunchKernelGGL(fill, dim3(4096), dim3(256), 0, 0, x, n);   // non-trivial data
+    (void)hipDeviceSynchronize();
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    auto run = [&](const char* name, auto launch) {
+        for (int r = 0; r < 2; ++r) launch();
+        hipDeviceSynchronize();
+        float best = 1e9, sum = 0;
+        for (int r = 0; r < 5; ++r) {
+            hipEventRecord(e0); launch(); hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1); best = ms < best ? ms : best; sum += ms;
+        }
+        printf("%-28s best %.3f ms %.0f GB/s   mean %.3f ms\n", name, best, n * 4 / best / 1e6, sum / 5);
+    };
+    (void)NB;
+    for (int grid : {1024, 2048, 4096}) {
+        char nm[64];
+#define RUN(K, U, NT) snprintf(nm, 64, #K "<" #U "," #NT "> grid %d", grid); run(nm, [&] { hipLaunchKernelGGL((K<U, NT>), dim3(grid), dim3(256), 0, 0, (const f4*)x, y, n / 4); });
+        RUN(rd, 1, false) RUN(rd, 4, false) RUN(rd, 8, false) RUN(rd, 4, true) RUN(rd, 8, true)
+        RUN(rdc, 4, false) RUN(rdc, 8, false) RUN(rdc, 8, true)
+    }
+    return 0;
+}
