@@ -59,6 +59,19 @@ constexpr int FRB = WM_FWD_RB;      // rows per load batch of the flat forward k
 #ifndef WM_FWD_XCD_RUN
 #define WM_FWD_XCD_RUN 16
 #endif
+// Non-temporal loads of the single-use rows in the flat stencil kernels, measured per kernel on
+// (64,1,721,1440) (tools/probe/stencil_time.py, same box): weight gradient 98.2 -> 91.4 us with its
+// finalize launch, forward 93.3 -> 92.0, backward-data 90.7 -> 102.6 (its halo pair re-reads the
+// neighbour lane's line): on, on, off.
+#ifndef WM_NT_FWD
+#define WM_NT_FWD true
+#endif
+#ifndef WM_NT_BWDW
+#define WM_NT_BWDW true
+#endif
+#ifndef WM_NT_BWDD
+#define WM_NT_BWDD false
+#endif
 #ifndef WM_BWD_OCC_CAP
 #define WM_BWD_OCC_CAP 6
 #endif
@@ -240,11 +253,18 @@ struct FlatOut {
     int mask;            // ring size - 1 (power of two)
 };
 
-template <int KH, int KW, int NB>
+// NT: non-temporal loads, for rows nobody reads again (a contiguous stream reads 12 % faster with
+// the nt bit on this chip, tools/probe/read_probe.hip).  The KH - 1 rows a range shares with its
+// successor are loaded normally by the range that meets them first (its tail), so that they stay
+// in L2 for the second reader.
+template <int KH, int KW, int NB, bool NT = false>
 __device__ __forceinline__ void load_rows_f(f32x4 (&rows)[NB], const float *__restrict__ p, int W)
 {
 #pragma unroll
-    for (int u = 0; u < NB; ++u) rows[u] = *reinterpret_cast<const f32x4 *>(p + (size_t)u * W);
+    for (int u = 0; u < NB; ++u) {
+        const f32x4 *q = reinterpret_cast<const f32x4 *>(p + (size_t)u * W);
+        rows[u] = NT ? __builtin_nontemporal_load(q) : *q;
+    }
 }
 
 // consume NB loaded rows: window shift, halo shuffle, outputs into the ring, then flush
@@ -378,14 +398,14 @@ __global__ __launch_bounds__(1024) void conv_fwd_c1f_kernel(
     // on a cool chip when the double-buffered batch went away).
     for (int bi = 0; bi < nfull; ++bi) {
         f32x4 cur[FRB];
-        load_rows_f<KH, KW, FRB>(cur, xq, W);
+        load_rows_f<KH, KW, FRB, WM_NT_FWD>(cur, xq, W);
         xq += (size_t)FRB * W;
         __builtin_amdgcn_sched_barrier(0);
         fwd_batch_f<KH, KW, FRB>(cur, ring, fo, win, wr, bias, relu, j0, nst, h, hmin, H, OW);
     }
     for (int s = nfull * FRB; s < main_steps; ++s) {
         f32x4 one[1];
-        load_rows_f<KH, KW, 1>(one, xq, W);
+        load_rows_f<KH, KW, 1, WM_NT_FWD>(one, xq, W);
         xq += W;
         fwd_batch_f<KH, KW, 1>(one, ring, fo, win, wr, bias, relu, j0, nst, h, hmin, H, OW);
     }
@@ -514,8 +534,10 @@ __device__ __forceinline__ void bwd_batch_f(const float *__restrict__ &xq,
     bool prod[NB];
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
-        rows[u] = *reinterpret_cast<const f32x4 *>(xq + (size_t)u * W);
-        gv[u] = *reinterpret_cast<const f4u *>(gq);     // ignored on a non-producing step
+        const f32x4 *xp_ = reinterpret_cast<const f32x4 *>(xq + (size_t)u * W);
+        const f4u *gp_ = reinterpret_cast<const f4u *>(gq);
+        rows[u] = WM_NT_BWDW ? __builtin_nontemporal_load(xp_) : *xp_;
+        gv[u] = WM_NT_BWDW ? __builtin_nontemporal_load(gp_) : *gp_;     // ignored on a non-producing step
         prod[u] = h >= hmin;
         gq += prod[u] ? OW : 0;
         const bool wrap = (h + 1 == H);
@@ -649,7 +671,7 @@ __device__ __forceinline__ void virtual_row(long long v, int H, int OH, int &p, 
     }
 }
 
-template <int NB>
+template <int NB, bool NT = false>
 __device__ __forceinline__ void load_gy_rows(GyRow (&rows)[NB], const float *__restrict__ gy,
                                              int OW, int OH, int H, unsigned last_row, int jg,
                                              int jh, int &p, unsigned &gr)
@@ -658,7 +680,8 @@ __device__ __forceinline__ void load_gy_rows(GyRow (&rows)[NB], const float *__r
     for (int u = 0; u < NB; ++u) {
         const bool valid = p >= 0 && p < OH;
         const size_t row = (size_t)min(gr, last_row) * OW;     // always in bounds; zeroed if !valid
-        rows[u].own = *reinterpret_cast<const f4u *>(gy + row + jg);
+        const f4u *own_ = reinterpret_cast<const f4u *>(gy + row + jg);
+        rows[u].own = NT ? __builtin_nontemporal_load(own_) : *own_;      // see load_rows_f
         rows[u].halo = *reinterpret_cast<const f2u *>(gy + row + jh);
         rows[u].valid = valid;
         gr += valid ? 1u : 0u;
@@ -771,13 +794,13 @@ __global__ __launch_bounds__(1024) void conv_bwd_data_c1f_kernel(
     const int nfull = main_steps / FRB;
     for (int bi = 0; bi < nfull; ++bi) {
         GyRow cur[FRB];
-        load_gy_rows<FRB>(cur, gy, OW, OH, H, last_row, jg, jh, p, gr);
+        load_gy_rows<FRB, WM_NT_BWDD>(cur, gy, OW, OH, H, last_row, jg, jh, p, gr);
         __builtin_amdgcn_sched_barrier(0);
         bwd_data_batch<KH, KW, FRB>(cur, gq, win, wr, shift, has_halo, active, skip, W);
     }
     for (int s = nfull * FRB; s < main_steps; ++s) {
         GyRow one[1];
-        load_gy_rows<1>(one, gy, OW, OH, H, last_row, jg, jh, p, gr);
+        load_gy_rows<1, WM_NT_BWDD>(one, gy, OW, OH, H, last_row, jg, jh, p, gr);
         bwd_data_batch<KH, KW, 1>(one, gq, win, wr, shift, has_halo, active, skip, W);
     }
     if constexpr (TR > 0)

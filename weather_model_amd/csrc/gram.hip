@@ -303,8 +303,8 @@ __global__ __launch_bounds__(BLOCK, 2) void gram_x64_kernel(const float *__restr
         float yv[X64_UNROLL];
 #pragma unroll
         for (int u = 0; u < X64_UNROLL; ++u) {
-            xv[u] = Xv[(s + u) * 64 + lane];
-            yv[u] = Y[(s + u) * 4 + g];
+            xv[u] = __builtin_nontemporal_load(Xv + (s + u) * 64 + lane);     // streamed once
+            yv[u] = __builtin_nontemporal_load(Y + (s + u) * 4 + g);
         }
 #pragma unroll
         for (int u = 0; u < X64_UNROLL; ++u) x64_step(a, xv[u], yv[u]);
