@@ -53,8 +53,13 @@ constexpr int RB = WM_STENCIL_RB;
 #define WM_FWD_RB 2
 #endif
 constexpr int FRB = WM_FWD_RB;      // rows per load batch of the flat forward kernel
+// load batches of FRB rows per range: with non-temporal main loads the forward is fastest at
+// three (89-91 us against 92-93 at two), backward-data at two (90 against 94)
 #ifndef WM_FWD_BATCHES
-#define WM_FWD_BATCHES 2
+#define WM_FWD_BATCHES 3
+#endif
+#ifndef WM_BWDD_BATCHES
+#define WM_BWDD_BATCHES 2
 #endif
 #ifndef WM_FWD_XCD_RUN
 #define WM_FWD_XCD_RUN 16
@@ -65,6 +70,9 @@ constexpr int FRB = WM_FWD_RB;      // rows per load batch of the flat forward k
 // neighbour lane's line): on, on, off.
 #ifndef WM_NT_FWD
 #define WM_NT_FWD true
+#endif
+#ifndef WM_NT_FWD_TAIL
+#define WM_NT_FWD_TAIL false
 #endif
 #ifndef WM_NT_BWDW
 #define WM_NT_BWDW true
@@ -387,7 +395,7 @@ __global__ __launch_bounds__(1024) void conv_fwd_c1f_kernel(
     constexpr int TR = KH - 1;
     f32x4 tail[TR > 0 ? TR : 1];
     if constexpr (TR > 0) {
-        load_rows_f<KH, KW, TR>(tail, xq + (size_t)(steps - TR) * W, W);
+        load_rows_f<KH, KW, TR, WM_NT_FWD_TAIL>(tail, xq + (size_t)(steps - TR) * W, W);
         __builtin_amdgcn_sched_barrier(0);
     }
     const int main_steps = steps - TR;
@@ -1227,7 +1235,7 @@ extern "C" int wm_conv2d_bwd_data_f32(const float *gy, const float *w, float *gx
     if (stencil_shape(Cin, Cout, kH, kW, OW, (long long)N * H) && kH * kW <= 9 && kW <= 3 &&
         W % 4 == 0 && OW >= 4 && W <= 4096 && ((uintptr_t)gx & 15) == 0) {
         const long long total_rows = (long long)N * H;
-        const int rows = WM_KNOB(WM_FWD_BATCHES) * FRB;
+        const int rows = WM_KNOB(WM_BWDD_BATCHES) * FRB;
         const long long segs = (total_rows + rows - 1) / rows;
         if (segs <= 0x7fffffffLL) {
             const unsigned rows_base = (unsigned)(total_rows / segs);
