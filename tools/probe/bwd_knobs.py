@@ -65,7 +65,7 @@ def run():
             print(f"bwd_data xcd {xr} batches {nb}: {burst([bwdd]):6.1f} us  fwd+bwd+bwdd {burst([fwd, bwd, bwdd]):6.1f} ok={ok}", flush=True)
         return
     ref = None
-    for cap in (3, 6):
+    for cap in (2, 3, 4, 6, 8):
         os.environ["WM_BWD_OCC_CAP"] = str(cap)
         bwd(0); torch.cuda.synchronize()
         if ref is None: ref = gw.clone()
