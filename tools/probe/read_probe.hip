@@ -45,6 +45,20 @@ __global__ void fill(float* x, long long n) {
         x[i] = (float)(h >> 8) * (1.0f / 16777216.0f);
     }
 }
+// copy: each wave owns a contiguous range, U KiB-chunks in flight
+template <int U, bool NTL, bool NTS>
+__global__ __launch_bounds__(256) void cpc(const f4* __restrict__ in, f4* __restrict__ out, long long n4) {
+    const long long nw = (long long)gridDim.x * 4, w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long t0 = (n4 / 64) * w / nw, t1 = (n4 / 64) * (w + 1) / nw;
+    const int lane = threadIdx.x & 63;
+    for (long long t = t0; t + U <= t1; t += U) {
+        f4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = NTL ? __builtin_nontemporal_load(in + (t + u) * 64 + lane) : in[(t + u) * 64 + lane];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { if (NTS) __builtin_nontemporal_store(v[u], out + (t + u) * 64 + lane); else out[(t + u) * 64 + lane] = v[u]; }
+    }
+}
 int main() {
     const long long n = 1700000000ll;          // 6.8 GB, the gram16 working set
     const int NB = 1;
@@ -69,6 +83,15 @@ int main() {
 #define RUN(K, U, NT) snprintf(nm, 64, #K "<" #U "," #NT "> grid %d", grid); run(nm, [&] { hipLaunchKernelGGL((K<U, NT>), dim3(grid), dim3(256), 0, 0, (const f4*)x, y, n / 4); });
         RUN(rd, 1, false) RUN(rd, 4, false) RUN(rd, 8, false) RUN(rd, 4, true) RUN(rd, 8, true)
         RUN(rdc, 4, false) RUN(rdc, 8, false) RUN(rdc, 8, true)
+    }
+    {
+        const long long h = n / 2;              // 3.4 GB in, 3.4 GB out
+        f4 *src = (f4*)x, *dst = (f4*)(x + h);
+        for (int grid : {768, 1024, 2048, 4096}) {
+            char nm[64];
+#define RUNC(U, A, B) snprintf(nm, 64, "copy<" #U "," #A "," #B "> grid %d", grid); run(nm, [&] { hipLaunchKernelGGL((cpc<U, A, B>), dim3(grid), dim3(256), 0, 0, (const f4*)src, dst, h / 4); });
+            RUNC(4, false, true) RUNC(4, true, true) RUNC(8, true, true) RUNC(8, true, false)
+        }
     }
     return 0;
 }
