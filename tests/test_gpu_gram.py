@@ -68,7 +68,9 @@ def test_gram_is_a_running_sum_and_reproducible():
     whole = ops.gram(Xd, Yd)
     acc = ops.gram(Xd[:20000], Yd[:20000])
     acc = ops.gram(Xd[20000:], Yd[20000:], acc)
-    assert relinf(acc.cpu().numpy(), whole.cpu().numpy()) < 1e-9
+    # float32 products summed in float32 for up to 1024 rows per accumulator (include/wm.h), then
+    # float64: two splits of the rows associate those float32 sums differently
+    assert relinf(acc.cpu().numpy(), whole.cpu().numpy()) < 1e-7
     assert torch.equal(ops.gram(Xd, Yd), whole)           # bitwise reproducible
     # rows may arrive in any order: the sufficient statistic is permutation invariant
     perm = torch.randperm(50000, device="cuda")

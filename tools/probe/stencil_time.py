@@ -24,8 +24,9 @@ def fwd(k): _lib.check(L.wm_conv2d_fwd_f32(xs[k].data_ptr(), w.data_ptr(), b.dat
 def bww(k): _lib.check(L.wm_conv2d_bwd_wb_f32(xs[k].data_ptr(), gys[k].data_ptr(), grads.data_ptr(), grads[9:].data_ptr(), ws.data_ptr(), ws.numel(), N, 1, H, W, 1, 3, 3, st))
 def bwd(k): _lib.check(L.wm_conv2d_bwd_data_f32(gys[k].data_ptr(), w.data_ptr(), gxs[k].data_ptr(), N, 1, H, W, 1, 3, 3, st))
 def pair(k): fwd(k); bww(k)
+def trio(k): fwd(k); bww(k); bwd(k)
 out = []
-for name, fn in (("fwd", fwd), ("bwd_wb", bww), ("bwd_data", bwd), ("pair", pair)):
+for name, fn in (("fwd", fwd), ("bwd_wb", bww), ("bwd_data", bwd), ("pair", pair), ("trio", trio)):
     for i in range(4): fn(i % nset)
     torch.cuda.synchronize()
     res = []

@@ -109,8 +109,6 @@ __global__ __launch_bounds__(BLOCK, 2) void gram_f16_kernel(const float *__restr
     const long long wave_id = (long long)blockIdx.x * WAVES + wv;
     const long long tiles = (n + 15) >> 4;          // 16-row tiles, the last may be partial
     const long long full_tiles = n >> 4;
-    const long long t0 = tiles * wave_id / nwaves;
-    const long long t1 = tiles * (wave_id + 1) / nwaves;
 
     F16Acc a;
     f16_zero(a);
@@ -120,10 +118,16 @@ __global__ __launch_bounds__(BLOCK, 2) void gram_f16_kernel(const float *__restr
 
     const f32x4 *__restrict__ Xv = reinterpret_cast<const f32x4 *>(X);
     const int rsub = lane >> 2;
-    long long t = t0;
     int since_flush = 0;
-    const long long t1_full = (t1 < full_tiles) ? t1 : full_tiles;
-    for (; t + F16_UNROLL <= t1_full; t += F16_UNROLL) {
+    // Batches of F16_UNROLL tiles (8 KiB of X) are dealt to the waves round-robin, so the waves that
+    // are active together read ONE compact window that moves through X.  Giving every wave a
+    // contiguous range instead (ranges 3.3 MB apart) was 4-5 % slower on the same box (1.131 ->
+    // 1.078 ms at n = 1e8, tools/probe/gram16_time.py), and runs of 4 or 16 batches per wave far
+    // slower (1.43 / 1.35 ms); batch sizes of 4 to 12 tiles and 3 or 4 waves per SIMD (float64
+    // sums moved to LDS) all ran within 1 % of this.
+    const long long nb = full_tiles / F16_UNROLL;
+    for (long long b = wave_id; b < nb; b += nwaves) {
+        const long long t = b * F16_UNROLL;
         f32x4 xv[F16_UNROLL];
         float yv[F16_UNROLL];
 #pragma unroll
@@ -141,7 +145,8 @@ __global__ __launch_bounds__(BLOCK, 2) void gram_f16_kernel(const float *__restr
             since_flush = 0;
         }
     }
-    for (; t < t1; ++t) {
+    // the at most F16_UNROLL tiles behind the last full batch (the last may be partial): one per wave
+    for (long long t = nb * F16_UNROLL + wave_id; t < tiles; t += nwaves) {
         const long long row = t * 16 + rsub;
         f32x4 xv = (f32x4){0.f, 0.f, 0.f, 0.f};
         float yv = 0.f;
@@ -295,8 +300,8 @@ __global__ __launch_bounds__(BLOCK, 2) void gram_x64_kernel(const float *__restr
     for (int v = 0; v < X64_NVAL; ++v) d[v] = 0.0;
 
     const f32x4 *__restrict__ Xv = reinterpret_cast<const f32x4 *>(X);
-    long long s = s0;
     int since_flush = 0;
+    long long s = s0;
     const long long s1_full = (s1 < full_steps) ? s1 : full_steps;
     for (; s + X64_UNROLL <= s1_full; s += X64_UNROLL) {
         f32x4 xv[X64_UNROLL];
