@@ -39,6 +39,22 @@ __global__ __launch_bounds__(256) void rdc(const f4* __restrict__ in, float* __r
     for (; t < t1; ++t) s += in[t * 64 + lane];
     if (s.x + s.y + s.z + s.w == 12345.678f) out[0] = s.x;
 }
+// batches of U KiB-chunks dealt to the waves round-robin: the active waves read one compact window
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void rdr(const f4* __restrict__ in, float* __restrict__ out, long long n4) {
+    const long long nw = (long long)gridDim.x * 4, w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long nb = n4 / 64 / U;
+    const int lane = threadIdx.x & 63;
+    f4 s = {0, 0, 0, 0};
+    for (long long b = w; b < nb; b += nw) {
+        f4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = NT ? __builtin_nontemporal_load(in + (b * U + u) * 64 + lane) : in[(b * U + u) * 64 + lane];
+#pragma unroll
+        for (int u = 0; u < U; ++u) s += v[u];
+    }
+    if (s.x + s.y + s.z + s.w == 12345.678f) out[0] = s.x;
+}
 __global__ void fill(float* x, long long n) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         unsigned h = (unsigned)i * 2654435761u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
@@ -78,11 +94,12 @@ int main() {
         printf("%-28s best %.3f ms %.0f GB/s   mean %.3f ms\n", name, best, n * 4 / best / 1e6, sum / 5);
     };
     (void)NB;
-    for (int grid : {1024, 2048, 4096}) {
+    for (int grid : {512, 1024, 2048, 4096}) {
         char nm[64];
 #define RUN(K, U, NT) snprintf(nm, 64, #K "<" #U "," #NT "> grid %d", grid); run(nm, [&] { hipLaunchKernelGGL((K<U, NT>), dim3(grid), dim3(256), 0, 0, (const f4*)x, y, n / 4); });
         RUN(rd, 1, false) RUN(rd, 4, false) RUN(rd, 8, false) RUN(rd, 4, true) RUN(rd, 8, true)
         RUN(rdc, 4, false) RUN(rdc, 8, false) RUN(rdc, 8, true)
+        RUN(rdr, 2, true) RUN(rdr, 4, true) RUN(rdr, 8, true) RUN(rdr, 8, false)
     }
     {
         const long long h = n / 2;              // 3.4 GB in, 3.4 GB out
