@@ -19,8 +19,11 @@ out = torch.zeros((5,), device="cuda", dtype=torch.float64)
 st = 0
 def stats(k): _lib.check(L.wm_field_stats_f32(xs[k].data_ptr(), n, out.data_ptr(), 0, ws.data_ptr(), ws.numel(), st))
 def norm(k): _lib.check(L.wm_affine_scale_f32(xs[k].data_ptr(), ys[k].data_ptr(), n, 0.25, 1.5, st))
+T, Z, Y, X, V = 9, 1, 721, 1440, 6
+vol = ops.synth_uniform((T, Z, Y, X, V), seed=80)
+def gath(k): ops.gather_triplets(vol, (T - 6, Z, Y, X), first=0, count=Y * X)
 res_s = []
-for name, fn in (("stats", stats), ("normalise", norm)):
+for name, fn in (("stats", stats), ("normalise", norm), ("gather", gath)):
     for i in range(4): fn(i % nset)
     torch.cuda.synchronize()
     res = []

@@ -80,6 +80,15 @@ constexpr int FRB = WM_FWD_RB;      // rows per load batch of the flat forward k
 #ifndef WM_NT_BWDD
 #define WM_NT_BWDD false
 #endif
+// relu_mask_kernel (three streams: g, mask, out): non-temporal on all three and 2 workgroups per CU
+// -- 572 -> 519 us on (8,32,721,1440); 4 per CU 555, 1 per CU 687 (tools/probe/mask_time.py): a
+// read+write stream on this chip wants few bytes in flight
+#ifndef WM_RM_NT
+#define WM_RM_NT 1
+#endif
+#ifndef WM_RM_CAP
+#define WM_RM_CAP 2
+#endif
 #ifndef WM_BWD_OCC_CAP
 #define WM_BWD_OCC_CAP 6
 #endif
@@ -1287,12 +1296,20 @@ __global__ __launch_bounds__(BLOCK) void relu_mask_kernel(const float *g, const 
     if (vec) {
         const long long n4 = n / 4;
         for (; i < n4; i += stride) {
+#if WM_RM_NT
+            const f32x4 gv = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(g) + i);
+#else
             const f32x4 gv = reinterpret_cast<const f32x4 *>(g)[i];
+#endif
             const f32x4 mv = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(m) + i);
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = mv[e] > 0.0f ? gv[e] : 0.0f;
+#if WM_RM_NT
+            __builtin_nontemporal_store(o, reinterpret_cast<f32x4 *>(out) + i);
+#else
             reinterpret_cast<f32x4 *>(out)[i] = o;
+#endif
         }
         i = n4 * 4 + (long long)blockIdx.x * BLOCK + threadIdx.x;
         if (blockIdx.x != 0) return;
@@ -1306,7 +1323,7 @@ static int relu_mask_launch(const float *g, const float *ymask, float *out, int6
     WM_REQUIRE(wm_num_cus() > 0, WM_ERR_NO_DEVICE, "wm_relu_mask_f32: no HIP device");
     const int vec = ((((uintptr_t)g | (uintptr_t)ymask | (uintptr_t)out) & 15) == 0) ? 1 : 0;
     long long grid = ((vec ? n / 4 : n) + BLOCK - 1) / BLOCK;
-    const long long cap = (long long)wm_num_cus() * 4;
+    const long long cap = (long long)wm_num_cus() * WM_RM_CAP;
     if (grid > cap) grid = cap;
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)grid), dim3(BLOCK), 0, (hipStream_t)stream,

@@ -13,6 +13,14 @@ namespace {
 
 constexpr int BLOCK = 256;
 constexpr int NSTAT = 5;      // min, max, sum, sumsq, count
+// workgroups per CU of the read+write streams (tools/probe/fields_time.py, mask_time.py): normalise
+// 92.4-93.3 us at 8, 89.6-90.2 at 4 (1 GB: 395 -> 375); triplet gather 31.5-34 at 8, 28.5 at 2
+#ifndef WM_AFFINE_CAP
+#define WM_AFFINE_CAP 4
+#endif
+#ifndef WM_GATHER_CAP
+#define WM_GATHER_CAP 2
+#endif
 #ifndef WM_STAT_U
 #define WM_STAT_U 4
 #endif
@@ -325,10 +333,10 @@ __global__ __launch_bounds__(BLOCK) void gather_cubes_kernel(
     }
 }
 
-int stream_grid(long long work_items)
+int stream_grid(long long work_items, int per_cu = 8)
 {
     long long g = (work_items + BLOCK - 1) / BLOCK;
-    const long long cap = (long long)wm_num_cus() * 8;
+    const long long cap = (long long)wm_num_cus() * per_cu;
     if (g > cap) g = cap;
     if (g < 1) g = 1;
     return (int)g;
@@ -375,7 +383,7 @@ extern "C" int wm_affine_scale_f32(const float *x, float *y, int64_t n, float of
                "wm_affine_scale_f32: x and y must be 16-byte aligned");
     if (n == 0) return WM_OK;
     WM_REQUIRE(wm_num_cus() > 0, WM_ERR_NO_DEVICE, "wm_affine_scale_f32: no HIP device");
-    hipLaunchKernelGGL(affine_scale_kernel, dim3(stream_grid(n / 4 + 1)), dim3(BLOCK), 0,
+    hipLaunchKernelGGL(affine_scale_kernel, dim3(stream_grid(n / 4 + 1, WM_AFFINE_CAP)), dim3(BLOCK), 0,
                        (hipStream_t)stream, x, y, (long long)n, offset, divisor);
     WM_LAUNCH_CHECK("affine_scale_kernel");
     return WM_OK;
@@ -407,7 +415,7 @@ extern "C" int wm_gather_triplets_f32(const float *vol, const int64_t *idx, int6
         const long long last = idx ? tot : idx0 + B;          // largest sample id formed in 32 bits
         if (units < (1ll << 31) && plane < (1ll << 31) && tot < (1ll << 31) &&
             last < (1ll << 32)) {
-            const int grid = stream_grid(units);
+            const int grid = stream_grid(units, WM_GATHER_CAP);
             if (vec == 2)
                 hipLaunchKernelGGL(gather_triplets_u32_kernel<2>, dim3(grid), dim3(BLOCK), 0,
                                    (hipStream_t)stream, vol, (const long long *)idx,

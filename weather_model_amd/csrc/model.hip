@@ -37,7 +37,6 @@ constexpr int THREADS = WM_MODEL_THREADS;
 constexpr int WAVES = THREADS / 64;
 constexpr int NTILES = 74;      // weight-gradient tiles
 constexpr int SLOTS = (NTILES + WAVES - 1) / WAVES;
-constexpr int L1F_R = 8 / WAVES;        // linear1 forward units (j-tile, w-half) per wave
 
 static_assert(WAVES == 8, "unit and gradient-tile assignment is written for 8 waves");
 constexpr int NPARAM = 20566;
