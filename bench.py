@@ -891,7 +891,8 @@ def run_conv3d_model(steps, warmup, batch=16):
 # ------------------------------------------------------------------------------ field kernels
 def run_fields(steps, warmup, rank, world, cpu_base):
     """one-pass statistics, normalise and the sample gather, each on a
-    64 x 721 x 1440 field (266 MB, 3 rotating copies) / one 721 x 1440 slice of samples."""
+    64 x 721 x 1440 field (266 MB, 3 rotating copies) / one 721 x 1440 slice of samples; row a9:
+    the regression generators' rows from a resident volume."""
     from weather_model_amd import ops
     n = 64 * 721 * 1440
     nset = 3
@@ -924,7 +925,8 @@ def run_fields(steps, warmup, rank, world, cpu_base):
     res = {
         "unit": "elements/s",
         "config": {"workload": "field kernels: stats + normalise over 64x721x1440 fp32, triplet "
-                               "gather of one 721x1440 slice (6 variables)"},
+                               "gather of one 721x1440 slice (6 variables), regression rows from a "
+                               "resident volume"},
         "stats": {"value": n * world / t_stat, "ms": t_stat * 1e3,
                   "roofline": {"bound": "hbm", "achieved": 4 * n / k_stat / 1e9,
                                "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -943,6 +945,28 @@ def run_fields(steps, warmup, rank, world, cpu_base):
                                 "kernel": "gather_triplets_kernel",
                                 "algorithmic_bytes_per_sample": 144}},
     }
+    # row a9: design-matrix rows of the regression generators (cube 1, 8 variables, 16 rows per
+    # batch, the region walk in closed form) from a resident volume stored point-major
+    del vol
+    files, nv, Zc, bs, length, count = 70, 8, 2, 16, 4, 65536
+    stored = ops.synth_uniform((Zc, Y, X, files, nv), seed=81, offset=rank * Zc * Y * X * files * nv)
+    pm = stored.permute(3, 4, 0, 1, 2)                  # logical (files, vars, Z, Y, X)
+    walk = {"batch": bs, "length": length, "index": 0, "region": (0, 0, 0), "dims": (Zc, Y, X)}
+    crow = count * bs
+    t_cub, k_cub = timed(lambda i: ops.gather_cubes(pm, (1, 1, 1), 3, 6, crow, walk=walk))
+    res["cubes"] = {"value": crow * world / t_cub, "unit": "rows/s", "ms": t_cub * 1e3,
+                    "roofline": {"bound": "hbm", "achieved": 24 * nv * crow / k_cub / 1e9,
+                                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": 24 * nv * crow / k_cub / 1e9 / HBM_PEAK_GBS,
+                                 "traffic": None, "kernel": "gather_cubes_kernel<true>",
+                                 "algorithmic_bytes_per_row": 24 * nv},
+                    "config": {"workload": f"regression rows [x(t) | x(t+6) ; x(t+3)]: {crow} rows "
+                                           f"of {nv} variables, cube 1, batches of {bs}, region walk "
+                                           "of multipleRegression.py:259-270 in closed form",
+                               "volume_layout": "point-major (Z,Y,X,files,vars), passed as a strided "
+                                                "view; the reference's row-major order makes every "
+                                                "element a 4-byte gather (same rows: 289 us vs 40)"}}
+    del stored, pm
     res["value"] = res["stats"]["value"]
     res["ms_per_step"] = (t_stat + t_norm + t_gath) * 1e3
     if cpu_base and rank == 0 and world == 1:
@@ -1123,7 +1147,8 @@ def main():
             out.update({"metric": "elements/s field statistics", "unit": "elements/s",
                         "value": fres["value"], "ms_per_step": fres["ms_per_step"],
                         "roofline": fres["stats"]["roofline"], "config": fres["config"],
-                        "normalise": fres["normalise"], "gather": fres["gather"]})
+                        "normalise": fres["normalise"], "gather": fres["gather"],
+                        "cubes": fres["cubes"]})
             if "cpu_baseline" in fres:
                 out["cpu_baseline"] = fres["cpu_baseline"]
         else:

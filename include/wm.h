@@ -262,6 +262,21 @@ int wm_gather_cubes_f32(const float *vol, int files, int nvars, int Z, int Y, in
                         int dim_z, int dim_y, int dim_x,
                         float *x1out, float *x2out, int64_t xstride, float *yout, void *stream);
 
+/* The same rows from a resident volume in ANY layout: strides[5] (host memory) are the element
+ * strides of the (file, variable, z, y, x) axes, all >= 0.  wm_gather_cubes_f32 is this call with the
+ * row-major strides of the reference's arrays.  With cube 1 every element of a row comes from its
+ * own (file, variable) plane, a 4-byte gather per element in the row-major layout; a volume kept
+ * point-major -- (Z, Y, X, files, nvars), strides {nvars, 1, Y*X*files*nvars, X*files*nvars,
+ * files*nvars} -- makes the `batch` rows of a generator batch one contiguous read
+ * (multipleRegression.py:217-257 slices the same values file by file). */
+int wm_gather_cubes_strided_f32(const float *vol, int files, int nvars, int Z, int Y, int X,
+                                const int64_t *strides, int cz, int cy, int cx, int d_mid,
+                                int d_end, const int32_t *origins, int64_t rows, int batch,
+                                int64_t length, int64_t index0, int64_t r0, int64_t r1, int64_t r2,
+                                int dim_z, int dim_y, int dim_x,
+                                float *x1out, float *x2out, int64_t xstride, float *yout,
+                                void *stream);
+
 /* ------------------------------------------------------------------ synthetic data ------ */
 
 /* Counter-based generator: element i of `out` depends only on (seed, offset + i).  Same hash as

@@ -209,6 +209,17 @@ def test_device_rows_bit_exact_vs_host_generator():
         assert np.array_equal(Yd, y.astype(np.float32))
         assert dev.get_state() == host.get_state()
         assert host.region_index[0] >= 9 and host.region_index[1] >= 1
+        # a generator state beyond 2^31 batches: the kernel's 64-bit walk (the run above took
+        # the 31-bit fast path)
+        far = (2 ** 31 + 7, ((2 ** 31 + 7) // length, 2 ** 31 + 1, 5))
+        host.set_state(far)
+        dev.set_state(far)
+        x1, x2, y = host.rows(length + 2)
+        Xh = np.concatenate([x1.reshape(len(x1), -1), x2.reshape(len(x2), -1)], axis=1)
+        Xd, Yd = dev.device_rows(length + 2)
+        assert np.array_equal(Xd.cpu().numpy(), Xh.astype(np.float32))
+        assert np.array_equal(Yd.cpu().numpy(), y.astype(np.float32))
+        assert dev.get_state() == host.get_state()
 
 
 def test_gather_cubes_explicit_origins_and_errors():
@@ -238,6 +249,45 @@ def test_gather_cubes_explicit_origins_and_errors():
         ops.gather_cubes(torch.from_numpy(vol).cuda(), (1, 1, 1), 3, 6, 16,
                          walk={"batch": 16, "length": 4, "index": 0, "region": (0, 0, 0),
                                "dims": (2, 2, 2)})
+
+
+def test_gather_cubes_point_major_view_matches_row_major():
+    """wm_gather_cubes_strided_f32: the same logical volume stored point-major (Z, Y, X, files,
+    vars) and passed as a strided view gives bit-identical rows -- the four-variables-per-thread
+    path (cube 1, 8 variables), the scalar strided path (cube 2, 3 variables) and explicit origins."""
+    from weather_model_amd import ops, synth
+    for nv, cube, bs in ((8, 1, 16), (3, 2, 4), (4, 1, 5)):
+        files, Z, Y, X = 40, 5, 9, 12
+        host = synth.uniform(17 + nv, (files, nv, Z, Y, X))
+        rowmajor = torch.from_numpy(host).cuda()
+        stored = torch.from_numpy(np.ascontiguousarray(host.transpose(2, 3, 4, 0, 1))).cuda()
+        view = stored.permute(3, 4, 0, 1, 2)
+        assert view.shape == rowmajor.shape and not view.is_contiguous()
+        length = (files - 6) // bs
+        walk = {"batch": bs, "length": length, "index": 3, "region": (1, 0, 0),
+                "dims": (Z - cube + 1, Y - cube + 1, X - cube + 1)}
+        rows = bs * (7 * length + 2)
+        a = ops.gather_cubes(rowmajor, (cube,) * 3, 3, 6, rows, walk=walk)
+        b = ops.gather_cubes(view, (cube,) * 3, 3, 6, rows, walk=walk)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        # against numpy slicing for a few rows of the first batches (state (3; 1,0,0), length)
+        X0 = a[0].cpu().numpy()
+        for r in (0, bs - 1, bs, 2 * bs + 1):
+            bq = r // bs
+            idx = 3 + bq
+            f = (idx % length) * bs + r % bs
+            R0 = 1 if bq == 0 else idx // length
+            z0 = R0 % (Z - cube + 1)
+            if bq <= 2:     # R1, R2 still come from the start state (0, 0) or from R0 = 1 // dim_z = 0
+                cut = lambda ff: host[ff, :, z0:z0 + cube, 0:cube, 0:cube].reshape(-1)   # noqa: E731
+                assert np.array_equal(X0[r], np.concatenate([cut(f), cut(f + 6)]))
+        rng = np.random.default_rng(nv)
+        org = np.stack([rng.integers(0, files - 6, 33), rng.integers(0, Z - cube + 1, 33),
+                        rng.integers(0, Y - cube + 1, 33), rng.integers(0, X - cube + 1, 33)],
+                       axis=1).astype(np.int32)
+        a = ops.gather_cubes(rowmajor, (cube,) * 3, 3, 6, 33, origins=org, separate=True)
+        b = ops.gather_cubes(view, (cube,) * 3, 3, 6, 33, origins=org, separate=True)
+        assert all(torch.equal(u, v) for u, v in zip(a, b))
 
 
 def test_fit_without_resident_rows_reports_gram_loss():

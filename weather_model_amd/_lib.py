@@ -50,6 +50,9 @@ SIGNATURES = {
     "wm_gather_triplets_f32": (c_int, [vp, vp, c_i64, vp, vp, c_i64] + [c_int] * 12 + [vp]),
     "wm_gather_cubes_f32": (c_int, [vp] + [c_int] * 10 + [vp, c_i64, c_int, c_i64, c_i64, c_i64,
                                     c_i64, c_i64, c_int, c_int, c_int, vp, vp, c_i64, vp, vp]),
+    "wm_gather_cubes_strided_f32": (c_int, [vp] + [c_int] * 5 + [vp] + [c_int] * 5 + [vp, c_i64, c_int,
+                                            c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_int,
+                                            vp, vp, c_i64, vp, vp]),
     "wm_synth_uniform_f32": (c_int, [vp, c_i64, c_u64, c_u64, c_f32, c_f32, vp]),
     "wm_synth_regression_f32": (c_int, [vp, vp, c_i64, c_int, c_int, c_u64, c_u64, vp, c_f32,
                                         c_f32, c_int, vp]),

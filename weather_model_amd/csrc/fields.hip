@@ -273,7 +273,30 @@ struct CubeWalk {
     long long length, index0, r0, r1, r2;
     int bs, dim_z, dim_y, dim_x;
 };
+// element strides of the volume's (file, variable, z, y, x) axes: the row-major layout of the
+// reference, or any other resident layout (wm_gather_cubes_strided_f32)
+struct CubeStrides {
+    long long f, v, z, y, x;
+};
 
+// Division by a launch-invariant divisor (Granlund-Montgomery, round-up form): exact for every
+// 32-bit unsigned dividend.  A hardware 32-bit division is ~30 instructions and a 64-bit one ~100;
+// the walk below takes nine per element and the kernel was bound by them (point-major volume,
+// 1 M rows of 8: 95 us with 64-bit divisions, 78 with 32-bit ones; see DESIGN.md for this form).
+struct FastDiv {
+    unsigned d, m, s1, s2;
+};
+__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv &f)
+{
+    const unsigned t = __umulhi(f.m, n);
+    return (t + ((n - t) >> f.s1)) >> f.s2;
+}
+struct CubeDivs {
+    FastDiv p, bs, length, dim_z, dim_y, dim_x, cx, cy, cz;
+};
+
+// walk state of batch b (see the comment above CubeWalk); I = long long, or unsigned-with-FastDiv
+// when every count fits 31 bits
 __device__ __forceinline__ long long walk_r0(const CubeWalk &w, long long b)
 {
     return b <= 0 ? w.r0 : (w.index0 + b) / w.length;
@@ -287,50 +310,108 @@ __device__ __forceinline__ long long walk_r2(const CubeWalk &w, long long b)
     return b <= 0 ? w.r2 : walk_r1(w, b - 1) / w.dim_y;
 }
 
+// VEC = 4: cube 1 with the variables of a point contiguous and 16-byte aligned (the point-major
+// volume): a thread moves four variables per time slice; p, the element count and dv.p are then in
+// units of VEC floats
+template <bool SMALL, int VEC>
 __global__ __launch_bounds__(BLOCK) void gather_cubes_kernel(
     const float *__restrict__ vol, int files, int nvars, int Z, int Y, int X, int cz, int cy,
     int cx, int d_mid, int d_end, const int *__restrict__ origins, long long rows, CubeWalk w,
-    float *__restrict__ x1out, float *__restrict__ x2out, long long xstride,
-    float *__restrict__ yout)
+    CubeStrides st, CubeDivs dv, float *__restrict__ x1out, float *__restrict__ x2out,
+    long long xstride, float *__restrict__ yout)
 {
-    const int p = nvars * cz * cy * cx;
+    const int p = nvars * cz * cy * cx / VEC;
     const long long total = rows * p;
-    const long long fplane = (long long)nvars * Z * Y * X;
     const int dmax = d_mid > d_end ? d_mid : d_end;
     for (long long e = (long long)blockIdx.x * BLOCK + threadIdx.x; e < total;
          e += (long long)gridDim.x * BLOCK) {
-        const long long r = e / p;
-        int q = (int)(e - r * p);
-        long long f;
-        int z0, y0, x0;
+        long long r, f;
+        int q, z0, y0, x0;
+        if constexpr (SMALL) {
+            const unsigned eu = (unsigned)e, ru = fdiv(eu, dv.p);
+            r = ru;
+            q = (int)(eu - ru * (unsigned)p);
+            if (!origins) {
+                const unsigned b = fdiv(ru, dv.bs), ib = (unsigned)w.index0 + b;
+                const unsigned R0 = fdiv(ib, dv.length);
+                f = (long long)((ib - R0 * (unsigned)w.length) * (unsigned)w.bs +
+                                (ru - b * (unsigned)w.bs));
+                // R1_b = R0_{b-1} / dim_z, R2_b = (R0_{b-2} / dim_z) / dim_y; raw state for b <= 0
+                const unsigned R0m1 = b >= 1 ? fdiv(ib - 1, dv.length) : 0u;
+                const unsigned R0m2 = b >= 2 ? fdiv(ib - 2, dv.length) : 0u;
+                const unsigned r0 = b == 0 ? (unsigned)w.r0 : R0;
+                const unsigned r1 = b == 0 ? (unsigned)w.r1
+                                           : fdiv(b == 1 ? (unsigned)w.r0 : R0m1, dv.dim_z);
+                const unsigned r1m1 = b <= 1 ? (unsigned)w.r1
+                                             : fdiv(b == 2 ? (unsigned)w.r0 : R0m2, dv.dim_z);
+                const unsigned r2 = b == 0 ? (unsigned)w.r2 : fdiv(r1m1, dv.dim_y);
+                z0 = (int)(r0 - fdiv(r0, dv.dim_z) * (unsigned)w.dim_z);
+                y0 = (int)(r1 - fdiv(r1, dv.dim_y) * (unsigned)w.dim_y);
+                x0 = (int)(r2 - fdiv(r2, dv.dim_x) * (unsigned)w.dim_x);
+            }
+        } else {
+            r = e / p;
+            q = (int)(e - r * p);
+            if (!origins) {
+                const long long b = r / w.bs;
+                f = ((w.index0 + b) % w.length) * w.bs + (r - b * w.bs);
+                z0 = (int)(walk_r0(w, b) % w.dim_z);
+                y0 = (int)(walk_r1(w, b) % w.dim_y);
+                x0 = (int)(walk_r2(w, b) % w.dim_x);
+            }
+        }
         if (origins) {
             f = origins[4 * r];
             z0 = origins[4 * r + 1];
             y0 = origins[4 * r + 2];
             x0 = origins[4 * r + 3];
-        } else {
-            const long long b = r / w.bs;
-            f = ((w.index0 + b) % w.length) * w.bs + (r - b * w.bs);
-            z0 = (int)(walk_r0(w, b) % w.dim_z);
-            y0 = (int)(walk_r1(w, b) % w.dim_y);
-            x0 = (int)(walk_r2(w, b) % w.dim_x);
         }
         // the host validated the ranges; clamping keeps a bad origin from faulting the GPU
         f = max(0ll, min(f, (long long)files - 1 - dmax));
         z0 = max(0, min(z0, Z - cz));
         y0 = max(0, min(y0, Y - cy));
         x0 = max(0, min(x0, X - cx));
-        const int ix = q % cx; q /= cx;
-        const int iy = q % cy; q /= cy;
-        const int iz = q % cz;
-        const int v = q / cz;
-        const float *src = vol + f * fplane +
-                           (((long long)v * Z + z0 + iz) * Y + y0 + iy) * X + x0 + ix;
-        const long long o = e - r * p;
-        x1out[r * xstride + o] = src[0];
-        x2out[r * xstride + o] = src[(long long)d_end * fplane];
-        yout[r * p + o] = src[(long long)d_mid * fplane];
+        const int o = q * VEC;
+        int ix, iy, iz, v;
+        if constexpr (VEC > 1) {
+            ix = iy = iz = 0;
+            v = o;
+        } else if constexpr (SMALL) {
+            unsigned t = (unsigned)q, u = fdiv(t, dv.cx);
+            ix = (int)(t - u * (unsigned)cx); t = u; u = fdiv(t, dv.cy);
+            iy = (int)(t - u * (unsigned)cy); t = u; u = fdiv(t, dv.cz);
+            iz = (int)(t - u * (unsigned)cz);
+            v = (int)u;
+        } else {
+            ix = q % cx; q /= cx;
+            iy = q % cy; q /= cy;
+            iz = q % cz;
+            v = q / cz;
+        }
+        const float *src = vol + f * st.f + v * st.v + (z0 + iz) * st.z + (y0 + iy) * st.y +
+                           (x0 + ix) * st.x;
+        if constexpr (VEC == 4) {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(src);
+            const f32x4 c = *reinterpret_cast<const f32x4 *>(src + d_end * st.f);
+            const f32x4 m = *reinterpret_cast<const f32x4 *>(src + d_mid * st.f);
+            __builtin_nontemporal_store(a, reinterpret_cast<f32x4 *>(x1out + r * xstride + o));
+            __builtin_nontemporal_store(c, reinterpret_cast<f32x4 *>(x2out + r * xstride + o));
+            __builtin_nontemporal_store(m, reinterpret_cast<f32x4 *>(yout + r * (long long)p * VEC + o));
+        } else {
+            x1out[r * xstride + o] = src[0];
+            x2out[r * xstride + o] = src[d_end * st.f];
+            yout[r * p + o] = src[d_mid * st.f];
+        }
     }
+}
+
+FastDiv fast_div(unsigned d)
+{
+    // l = ceil(log2 d); m = floor(2^32 (2^l - d) / d) + 1; q = (t + ((n - t) >> min(l,1))) >> max(l-1,0)
+    unsigned l = 0;
+    while (l < 32 && (1ull << l) < d) ++l;
+    const unsigned long long m = ((1ull << 32) * ((1ull << l) - d)) / d + 1;
+    return {d, (unsigned)m, l < 1 ? l : 1u, l > 0 ? l - 1 : 0u};
 }
 
 int stream_grid(long long work_items, int per_cu = 8)
@@ -450,7 +531,26 @@ extern "C" int wm_gather_cubes_f32(const float *vol, int files, int nvars, int Z
                                    int dim_y, int dim_x, float *x1out, float *x2out,
                                    int64_t xstride, float *yout, void *stream)
 {
+    const int64_t strides[5] = {(int64_t)nvars * Z * Y * X, (int64_t)Z * Y * X, (int64_t)Y * X, X, 1};
+    return wm_gather_cubes_strided_f32(vol, files, nvars, Z, Y, X, strides, cz, cy, cx, d_mid, d_end,
+                                       origins, rows, batch, length, index0, r0, r1, r2, dim_z,
+                                       dim_y, dim_x, x1out, x2out, xstride, yout, stream);
+}
+
+extern "C" int wm_gather_cubes_strided_f32(const float *vol, int files, int nvars, int Z, int Y,
+                                           int X, const int64_t *strides, int cz, int cy, int cx,
+                                           int d_mid, int d_end, const int32_t *origins,
+                                           int64_t rows, int batch, int64_t length, int64_t index0,
+                                           int64_t r0, int64_t r1, int64_t r2, int dim_z, int dim_y,
+                                           int dim_x, float *x1out, float *x2out, int64_t xstride,
+                                           float *yout, void *stream)
+{
     WM_REQUIRE(vol && x1out && x2out && yout, WM_ERR_INVALID, "wm_gather_cubes_f32: null pointer");
+    WM_REQUIRE(strides, WM_ERR_INVALID, "wm_gather_cubes_f32: null strides");
+    for (int a = 0; a < 5; ++a)
+        WM_REQUIRE(strides[a] >= 0, WM_ERR_INVALID, "wm_gather_cubes_f32: negative stride %lld",
+                   (long long)strides[a]);
+    const CubeStrides cs = {strides[0], strides[1], strides[2], strides[3], strides[4]};
     WM_REQUIRE(files > 0 && nvars > 0 && Z > 0 && Y > 0 && X > 0, WM_ERR_INVALID,
                "wm_gather_cubes_f32: bad volume shape");
     WM_REQUIRE(cz > 0 && cy > 0 && cx > 0 && cz <= Z && cy <= Y && cx <= X, WM_ERR_INVALID,
@@ -476,9 +576,29 @@ extern "C" int wm_gather_cubes_f32(const float *vol, int files, int nvars, int Z
                    "than the %d resident files", (long long)length, batch, dmax, files);
     }
     WM_REQUIRE(wm_num_cus() > 0, WM_ERR_NO_DEVICE, "wm_gather_cubes_f32: no HIP device");
-    hipLaunchKernelGGL(gather_cubes_kernel, dim3(stream_grid(rows * p)), dim3(BLOCK), 0,
-                       (hipStream_t)stream, vol, files, nvars, Z, Y, X, cz, cy, cx, d_mid, d_end,
-                       origins, (long long)rows, w, x1out, x2out, (long long)xstride, yout);
+    // 31-bit fast path: element count, the batch index reached by the walk and its state
+    const long long lim = 1ll << 31;
+    const long long last_b = origins ? 0 : index0 + rows / (batch > 0 ? batch : 1) + 2;
+    const bool small = rows * p < lim && rows < lim &&
+                       (origins || (last_b < lim && length < lim && r0 < lim && r1 < lim && r2 < lim &&
+                                    (length + 1) * batch < lim));
+    const unsigned ub = origins ? 1u : (unsigned)batch, ul = origins ? 1u : (unsigned)length;
+    // four variables per thread: cube 1, variables contiguous, everything 16-byte aligned
+    const bool vec4 = small && cz == 1 && cy == 1 && cx == 1 && nvars % 4 == 0 && cs.v == 1 &&
+                      cs.f % 4 == 0 && cs.z % 4 == 0 && cs.y % 4 == 0 && cs.x % 4 == 0 &&
+                      xstride % 4 == 0 &&
+                      (((uintptr_t)vol | (uintptr_t)x1out | (uintptr_t)x2out | (uintptr_t)yout) & 15) == 0;
+    const long long units = vec4 ? rows * (p / 4) : rows * p;
+    const CubeDivs dv = {fast_div((unsigned)(vec4 ? p / 4 : p)), fast_div(ub), fast_div(ul),
+                         fast_div((unsigned)(origins ? 1 : dim_z)),
+                         fast_div((unsigned)(origins ? 1 : dim_y)),
+                         fast_div((unsigned)(origins ? 1 : dim_x)), fast_div((unsigned)cx),
+                         fast_div((unsigned)cy), fast_div((unsigned)cz)};
+    auto kern = vec4 ? gather_cubes_kernel<true, 4>
+                     : (small ? gather_cubes_kernel<true, 1> : gather_cubes_kernel<false, 1>);
+    hipLaunchKernelGGL(kern, dim3(stream_grid(units, 4)), dim3(BLOCK), 0, (hipStream_t)stream, vol,
+                       files, nvars, Z, Y, X, cz, cy, cx, d_mid, d_end, origins, (long long)rows, w,
+                       cs, dv, x1out, x2out, (long long)xstride, yout);
     WM_LAUNCH_CHECK("gather_cubes_kernel");
     return WM_OK;
 }

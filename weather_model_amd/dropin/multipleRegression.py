@@ -238,7 +238,14 @@ class WeatherDataGenerator:
             tested = [d for d in DATA_VARS if VARIABLE_TEST[self.iteration][d]]
             host = np.stack([np.stack([np.asarray(f[d][0], dtype=np.float32) for d in tested])
                              for f in self.all_data])
-            vol = torch.from_numpy(np.ascontiguousarray(host)).to(device)
+            if CUBE_SIZE[self.iteration] == 1:
+                # cube 1: a row takes ONE value per (file, variable) plane.  Stored point-major,
+                # (Z, Y, X, files, vars), the rows of a batch (consecutive files at one grid point)
+                # are one contiguous read; the kernel sees the same logical axes through strides
+                stored = torch.from_numpy(np.ascontiguousarray(host.transpose(2, 3, 4, 0, 1)))
+                vol = stored.to(device).permute(3, 4, 0, 1, 2)
+            else:
+                vol = torch.from_numpy(np.ascontiguousarray(host)).to(device)
             self._vol = vol
         return vol
 

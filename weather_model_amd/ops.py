@@ -11,6 +11,8 @@ raises otherwise -- there is no CPU path in the product.
 """
 from __future__ import annotations
 
+import ctypes
+
 import torch
 
 from . import _lib
@@ -516,10 +518,17 @@ def gather_cubes(vol, cube, d_mid, d_end, rows, origins=None, walk=None, separat
     (``wm_gather_cubes_f32``).  ``cube`` = (cz, cy, cx).  Either ``origins`` -- an int32 (rows, 4)
     tensor/array of (file, z0, y0, x0) -- or ``walk`` = dict(batch, length, index, region=(r0,r1,r2),
     dims=(dim_z, dim_y, dim_x)), the generator state at the first batch.
+    ``vol`` may be any strided view with that logical shape (``wm_gather_cubes_strided_f32``): a
+    volume stored point-major, ``stored.permute(3, 4, 0, 1, 2)`` of a (Z, Y, X, files, nvars)
+    tensor, turns the 4-byte gathers of cube-1 rows into contiguous reads.
     Returns (X (rows, 2p), Y (rows, p)), or (x1 (rows, p), x2 (rows, p), Y) with ``separate``."""
-    vol = _req(vol, "volume")
+    if not isinstance(vol, torch.Tensor) or not vol.is_cuda or vol.dtype != torch.float32:
+        raise RuntimeError("volume must be a float32 CUDA tensor (there is no CPU fallback)")
     if vol.dim() != 5:
         raise ValueError(f"volume must be (files, nvars, Z, Y, X), got {tuple(vol.shape)}")
+    if min(vol.stride()) < 0:
+        raise ValueError("volume views with negative strides are not supported")
+    strides = (ctypes.c_int64 * 5)(*vol.stride())
     files, nvars, Z, Y, X = vol.shape
     cz, cy, cx = (int(v) for v in cube)
     p = nvars * cz * cy * cx
@@ -552,8 +561,9 @@ def gather_cubes(vol, cube, d_mid, d_end, rows, origins=None, walk=None, separat
             args = (0, rows, int(walk["batch"]), int(walk["length"]), int(walk["index"]), r0, r1, r2,
                     dz, dy, dx)
         with torch.cuda.device(dev):
-            _lib.check(_lib.lib().wm_gather_cubes_f32(
-                vol.data_ptr(), files, nvars, Z, Y, X, cz, cy, cx, int(d_mid), int(d_end), *args,
+            _lib.check(_lib.lib().wm_gather_cubes_strided_f32(
+                vol.data_ptr(), files, nvars, Z, Y, X, strides, cz, cy, cx, int(d_mid), int(d_end),
+                *args,
                 a.data_ptr(), b.data_ptr(), stride, Yo.data_ptr(), _stream()))
     return (x1, x2, Yo) if separate else (Xo, Yo)
 
