@@ -386,7 +386,10 @@ def run_gram64(steps, warmup, rank, world, cpu_base, rows_per_gpu, chunk_rows=50
         "roofline": {"bound": "mfma", "achieved": flops_exec * krate / 1e12,
                      "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                      "frac": flops_exec * krate / 1e12 / MFMA_F32_PEAK_TF,
-                     "traffic": None, "kernel": "gram_x64_kernel",
+                     "traffic": pmc_traffic(["gram_x64_kernel"], chunk == 50_000_000),
+                     "traffic_source": pmc_source(["gram_x64_kernel"], chunk == 50_000_000),
+                     "traffic_note": "HBM bytes per 5e7-row chunk launch (algorithmic: 260 B/row)",
+                     "kernel": "gram_x64_kernel",
                      "flops_per_row_executed": flops_exec,
                      "flops_per_row_full_product": flops_full,
                      "note": "frac uses the flops the kernel executes (10 of the 16 blocks of the "
@@ -530,7 +533,11 @@ def run_conv(steps, warmup, rank, world, cpu_base, N=64, H=721, W=1440):
         "roofline": {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "achieved": 3 * fwd_bytes / (trio_ms * 1e-3) / 1e9,
                      "frac": 3 * fwd_bytes / (trio_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                     "traffic": None, "kernel": "+ conv_bwd_data_c1f_kernel<3,3>",
+                     "traffic": pmc_traffic(kernels + ["conv_bwd_data_c1f_kernel<3, 3>"],
+                                            default_shape),
+                     "traffic_source": pmc_source(kernels + ["conv_bwd_data_c1f_kernel<3, 3>"],
+                                                  default_shape),
+                     "kernel": "+ conv_bwd_data_c1f_kernel<3,3>",
                      "algorithmic_bytes_per_point": 24}}
     del gxs
     if cpu_base and rank == 0 and world == 1:
@@ -930,19 +937,25 @@ def run_fields(steps, warmup, rank, world, cpu_base):
         "stats": {"value": n * world / t_stat, "ms": t_stat * 1e3,
                   "roofline": {"bound": "hbm", "achieved": 4 * n / k_stat / 1e9,
                                "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": 4 * n / k_stat / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                               "frac": 4 * n / k_stat / 1e9 / HBM_PEAK_GBS,
+                               "traffic": pmc_traffic(["field_stats_kernel"], True),
+                               "traffic_source": pmc_source(["field_stats_kernel"], True),
                                "kernel": "field_stats_kernel", "algorithmic_bytes_per_element": 4}},
         "normalise": {"value": n * world / t_norm, "ms": t_norm * 1e3,
                       "roofline": {"bound": "hbm", "achieved": 8 * n / k_norm / 1e9,
                                    "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                   "frac": 8 * n / k_norm / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                   "frac": 8 * n / k_norm / 1e9 / HBM_PEAK_GBS,
+                                   "traffic": pmc_traffic(["affine_scale_kernel"], True),
+                                   "traffic_source": pmc_source(["affine_scale_kernel"], True),
                                    "kernel": "affine_scale_kernel",
                                    "algorithmic_bytes_per_element": 8}},
         "gather": {"value": B * world / t_gath, "unit": "samples/s", "ms": t_gath * 1e3,
                    "roofline": {"bound": "hbm", "achieved": 144 * B / k_gath / 1e9,
                                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": 144 * B / k_gath / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                                "kernel": "gather_triplets_kernel",
+                                "frac": 144 * B / k_gath / 1e9 / HBM_PEAK_GBS,
+                                "traffic": pmc_traffic(["gather_triplets_u32_kernel<2>"], True),
+                                "traffic_source": pmc_source(["gather_triplets_u32_kernel<2>"], True),
+                                "kernel": "gather_triplets_u32_kernel<2>",
                                 "algorithmic_bytes_per_sample": 144}},
     }
     # row a9: design-matrix rows of the regression generators (cube 1, 8 variables, 16 rows per
