@@ -66,10 +66,14 @@ constexpr int FRB = WM_FWD_RB;      // rows per load batch of the flat forward k
 #endif
 // Non-temporal loads of the single-use rows in the flat stencil kernels, measured per kernel on
 // (64,1,721,1440) (tools/probe/stencil_time.py, same box): weight gradient 98.2 -> 91.4 us with its
-// finalize launch, forward 93.3 -> 92.0, backward-data 90.7 -> 102.6 (its halo pair re-reads the
-// neighbour lane's line): on, on, off.
+// finalize launch, forward 93.3 -> 92.0 (89.4 with three batches), backward-data 90.7 -> 102.6 (its
+// halo pair re-reads the neighbour lane's line).  The forward nevertheless loads TEMPORALLY: alone
+// it is 4 us slower (93.5), but the step it belongs to is faster -- forward + weight gradient of the
+// same x back to back 185.8-188.8 -> 182.8 us, with backward-data 285-289 -> 280.8 (in bench.py's
+// loop 189.9/187.2 -> 186.8/185.8 = 0.71 of HBM peak): the rows of x it leaves in the 256 MiB
+// Infinity Cache are rows the weight gradient does not fetch from HBM again.
 #ifndef WM_NT_FWD
-#define WM_NT_FWD true
+#define WM_NT_FWD false
 #endif
 #ifndef WM_NT_FWD_TAIL
 #define WM_NT_FWD_TAIL false
