@@ -81,6 +81,13 @@ constexpr int FRB = WM_FWD_RB;      // rows per load batch of the flat forward k
 #ifndef WM_NT_BWDW
 #define WM_NT_BWDW true
 #endif
+// gy in the weight gradient is loaded temporally: the kernel itself does not care (89.8 us either
+// way), but a backward-data pass that follows it re-reads gy, and the three passes of a step take
+// 278 -> 264 us when part of gy is still in the Infinity Cache (walking backward-data from the
+// last range to the first instead: 3 us slower)
+#ifndef WM_NT_BWDW_G
+#define WM_NT_BWDW_G false
+#endif
 #ifndef WM_NT_BWDD
 #define WM_NT_BWDD false
 #endif
@@ -558,7 +565,7 @@ __device__ __forceinline__ void bwd_batch_f(const float *__restrict__ &xq,
         const f32x4 *xp_ = reinterpret_cast<const f32x4 *>(xq + (size_t)u * W);
         const f4u *gp_ = reinterpret_cast<const f4u *>(gq);
         rows[u] = WM_NT_BWDW ? __builtin_nontemporal_load(xp_) : *xp_;
-        gv[u] = WM_NT_BWDW ? __builtin_nontemporal_load(gp_) : *gp_;     // ignored on a non-producing step
+        gv[u] = WM_NT_BWDW_G ? __builtin_nontemporal_load(gp_) : *gp_;   // ignored on a non-producing step
         prod[u] = h >= hmin;
         gq += prod[u] ? OW : 0;
         const bool wrap = (h + 1 == H);
