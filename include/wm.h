@@ -277,6 +277,19 @@ int wm_gather_cubes_strided_f32(const float *vol, int files, int nvars, int Z, i
                                 float *x1out, float *x2out, int64_t xstride, float *yout,
                                 void *stream);
 
+/* Loss, metrics and loss gradient of the Conv3D model's train step in one pass, replacing
+ * keras' compile(loss='mean_squared_error', metrics=['mean_absolute_error',
+ * 'mean_squared_logarithmic_error']) as fit() evaluates it (convolution.py:176-180, train_step
+ * :46-62).  pred is (B, P); y is (B, P).  broadcast != 0 scores every prediction against every
+ * target of the batch -- what the reference's (B, 1, P) targets do to the (B, P) predictions
+ * (SURVEY.md 2b); broadcast == 0 pairs row i with row i.  out3 = {mean (y-p)^2, mean |y-p|,
+ * mean (log1p(max(p,eps)) - log1p(max(y,eps)))^2} (device memory, 3 floats); grad (may be NULL) is
+ * d out3[0] / d pred, shape (B, P).  B <= 64.  Sums are float64 in a fixed order. */
+size_t wm_mse_metrics_workspace_bytes(int64_t P);
+int wm_mse_metrics_f32(const float *pred, const float *y, int B, int64_t P, int broadcast,
+                       float eps, float *grad, float *out3, void *workspace,
+                       size_t workspace_bytes, void *stream);
+
 /* ------------------------------------------------------------------ synthetic data ------ */
 
 /* Counter-based generator: element i of `out` depends only on (seed, offset + i).  Same hash as

@@ -177,3 +177,31 @@ def test_data_generator_device_batches_bit_exact():
     cv.compile_model(m)
     h = m.fit(dev, epochs=2, steps_per_epoch=2, verbose=0)
     assert len(h.history["loss"]) == 2 and np.isfinite(h.history["loss"]).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,P,broadcast", [(16, 8000, True), (5, 37, True), (33, 1000, True),
+                                           (64, 130, True), (16, 8000, False), (1, 3, True)])
+def test_fused_loss_metrics_and_gradient(B, P, broadcast):
+    """wm_mse_metrics_f32 against the tensor expressions of the model (keras' mean_squared_error
+    on (B,1,P) targets, mae, msle with the epsilon clip) and autograd's gradient, in float64."""
+    from weather_model_amd import ops
+    gen = torch.Generator().manual_seed(B * 1000 + P)
+    pred = (torch.rand((B, P), generator=gen) * 2.0 - 0.5)       # some values below the clip
+    y = torch.rand((B, P), generator=gen) * 1.5 - 0.25
+    out3, grad = ops.mse_metrics(pred.cuda(), y.cuda(), broadcast)
+    pd = pred.double().requires_grad_(True)
+    yd = y.double()
+    diff = (yd[None, :, :] - pd[:, None, :]) if broadcast else (yd - pd)
+    lp = torch.log1p(pd.clamp_min(1e-7))
+    ly = torch.log1p(yd.clamp_min(1e-7))
+    le = (lp[:, None, :] - ly[None, :, :]) if broadcast else (lp - ly)
+    ref = torch.stack([(diff ** 2).mean(), diff.abs().mean(), (le ** 2).mean()])
+    (gref,) = torch.autograd.grad(ref[0], pd)
+    got = out3.cpu().double()
+    assert torch.allclose(got, ref.detach(), rtol=2e-6, atol=0)
+    assert (grad.cpu().double() - gref).abs().max() <= 2e-6 * gref.abs().max()
+    again, _ = ops.mse_metrics(pred.cuda(), y.cuda(), broadcast, want_grad=False)
+    assert torch.equal(again, out3)                               # fixed-order sums
+    with pytest.raises(Exception, match="out of range"):
+        ops.mse_metrics(torch.zeros((65, 4), device="cuda"), torch.zeros((65, 4), device="cuda"), True)

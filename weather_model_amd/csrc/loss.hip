@@ -1,0 +1,151 @@
+// loss.hip -- the loss and metrics of the Conv3D interpolation model's train step in one pass
+// (convolution.py:176-180: compile(loss='mean_squared_error', metrics=[mae, msle])).
+//
+// keras.losses.mean_squared_error as the reference reaches it scores predictions (B, P) against
+// targets (B, 1, P): the subtraction broadcasts to (B, B, P), every prediction against every target
+// of the batch.  With `broadcast` = 0 the targets are (B, P) and pairs are (i, i).
+//   loss = mean (y_j - p_i)^2,  mae = mean |y_j - p_i|,
+//   msle = mean (log1p(max(p_i, eps)) - log1p(max(y_j, eps)))^2,
+//   grad[i] = d loss / d p_i = 2 / (pairs * P) * sum_j (p_i - y_j)
+// Framework glue takes ~20 element-wise launches over the (B, B, P) differences for this (90 us of a
+// 560 us step at batch 16); here a thread owns one column p, keeps the B targets of the column and
+// their logs in registers and walks the B predictions.  Sums are float32 per thread (<= B*B terms),
+// float64 from there on, combined in a fixed order (bitwise reproducible).
+#include "common.h"
+
+namespace {
+
+constexpr int BLOCK = 256;
+constexpr int MAXB = 64;          // batch rows held in registers per column
+
+// partial: [3][gridDim.x] float64
+template <int NB>   // NB >= B, a power of two: the register arrays are fully unrolled
+__global__ __launch_bounds__(BLOCK) void mse_metrics_kernel(const float *__restrict__ pred,
+                                                            const float *__restrict__ y, int B,
+                                                            long long P, int broadcast, float eps,
+                                                            float gscale, float *__restrict__ grad,
+                                                            double *__restrict__ partial)
+{
+    __shared__ double red[BLOCK / 64][3];
+    double se = 0.0, ae = 0.0, le = 0.0;
+    for (long long p = (long long)blockIdx.x * BLOCK + threadIdx.x; p < P;
+         p += (long long)gridDim.x * BLOCK) {
+        float s2 = 0.0f, s1 = 0.0f, sl = 0.0f;
+        if (broadcast) {
+            float yv[NB], ly[NB];
+            float ysum = 0.0f;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                yv[j] = j < B ? y[(long long)j * P + p] : 0.0f;
+                ly[j] = log1pf(fmaxf(yv[j], eps));
+                ysum += yv[j];
+            }
+#pragma unroll 1
+            for (int i = 0; i < B; ++i) {
+                const float pv = pred[(long long)i * P + p];
+                const float lp = log1pf(fmaxf(pv, eps));
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const float d = yv[j] - pv, e = lp - ly[j];
+                    const bool on = j < B;
+                    s2 += on ? d * d : 0.0f;
+                    s1 += on ? fabsf(d) : 0.0f;
+                    sl += on ? e * e : 0.0f;
+                }
+                if (grad) grad[(long long)i * P + p] = gscale * ((float)B * pv - ysum);
+            }
+        } else {
+#pragma unroll 1
+            for (int i = 0; i < B; ++i) {
+                const float pv = pred[(long long)i * P + p], yi = y[(long long)i * P + p];
+                const float d = yi - pv;
+                const float e = log1pf(fmaxf(pv, eps)) - log1pf(fmaxf(yi, eps));
+                s2 += d * d;
+                s1 += fabsf(d);
+                sl += e * e;
+                if (grad) grad[(long long)i * P + p] = gscale * (pv - yi);
+            }
+        }
+        se += (double)s2;
+        ae += (double)s1;
+        le += (double)sl;
+    }
+    se = wave_sum(se);
+    ae = wave_sum(ae);
+    le = wave_sum(le);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) {
+        red[wv][0] = se;
+        red[wv][1] = ae;
+        red[wv][2] = le;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < BLOCK / 64; ++w) s += red[w][threadIdx.x];
+        partial[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = s;
+    }
+}
+
+// out[k] = (fixed-order sum of partial[k][0..nparts)) / count;  one wave per output
+__global__ __launch_bounds__(64) void mse_metrics_finalize_kernel(const double *__restrict__ partial,
+                                                                  int nparts, double inv_count,
+                                                                  float *__restrict__ out)
+{
+    const int k = blockIdx.x;
+    double s = 0.0;
+    for (int p = threadIdx.x; p < nparts; p += 64) s += partial[(size_t)k * nparts + p];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) out[k] = (float)(s * inv_count);
+}
+
+int loss_grid(long long P)
+{
+    long long g = (P + BLOCK - 1) / BLOCK;
+    const long long cap = (long long)wm_num_cus() * 4;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+extern "C" size_t wm_mse_metrics_workspace_bytes(int64_t P)
+{
+    if (P <= 0 || wm_num_cus() <= 0) return 0;
+    return wm_align_up((size_t)loss_grid(P) * 3 * sizeof(double), 256);
+}
+
+extern "C" int wm_mse_metrics_f32(const float *pred, const float *y, int B, int64_t P,
+                                  int broadcast, float eps, float *grad, float *out3,
+                                  void *workspace, size_t workspace_bytes, void *stream)
+{
+    WM_REQUIRE(pred && y && out3, WM_ERR_INVALID, "wm_mse_metrics_f32: null pointer");
+    WM_REQUIRE(B > 0 && B <= MAXB && P > 0, WM_ERR_INVALID,
+               "wm_mse_metrics_f32: batch %d (1..%d) or row length %lld out of range", B, MAXB,
+               (long long)P);
+    WM_REQUIRE(wm_num_cus() > 0, WM_ERR_NO_DEVICE, "wm_mse_metrics_f32: no HIP device");
+    const size_t need = wm_mse_metrics_workspace_bytes(P);
+    WM_REQUIRE(workspace && workspace_bytes >= need, WM_ERR_WORKSPACE,
+               "wm_mse_metrics_f32: workspace of %zu bytes needed, %zu given", need, workspace_bytes);
+    const double pairs = broadcast ? (double)B * B : (double)B;
+    const double count = pairs * (double)P;
+    const float gscale = (float)(2.0 / count);
+    const int grid = loss_grid(P);
+    hipStream_t st = (hipStream_t)stream;
+    double *partial = (double *)workspace;
+#define WM_LOSS_LAUNCH(NB)                                                                     \
+    hipLaunchKernelGGL(mse_metrics_kernel<NB>, dim3(grid), dim3(BLOCK), 0, st, pred, y, B,      \
+                       (long long)P, broadcast, eps, gscale, grad, partial)
+    if (B <= 8) WM_LOSS_LAUNCH(8);
+    else if (B <= 16) WM_LOSS_LAUNCH(16);
+    else if (B <= 32) WM_LOSS_LAUNCH(32);
+    else WM_LOSS_LAUNCH(64);
+#undef WM_LOSS_LAUNCH
+    WM_LAUNCH_CHECK("mse_metrics_kernel");
+    hipLaunchKernelGGL(mse_metrics_finalize_kernel, dim3(3), dim3(64), 0, st, partial, grid,
+                       1.0 / count, out3);
+    WM_LAUNCH_CHECK("mse_metrics_finalize_kernel");
+    return WM_OK;
+}

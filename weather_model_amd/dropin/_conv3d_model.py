@@ -10,8 +10,9 @@ axis is left alone -> (B,16,7,7,14); the second conv then sees 16 input channels
 That is reproduced (``pool_channels_last=True``); ``False`` gives the presumably intended pool.
 
 Convolutions, pools and their gradients are the hand-written kernels (``ops.conv3d``,
-``ops.maxpool3d``); the two Dense layers are plain library GEMMs (``torch.nn.functional.linear`` =
-rocBLAS/hipBLASLt) and Adam is ``torch.optim.Adam`` with Keras' epsilon.  No CPU path.
+``ops.maxpool3d``), loss + metrics + loss gradient are one hand-written pass (``ops.mse_metrics``);
+the two Dense layers are plain library GEMMs (``torch.nn.functional.linear`` = rocBLAS/hipBLASLt)
+and Adam is ``torch.optim.Adam`` with Keras' epsilon.  No CPU path.
 
 Parity: unpinned against the reference's own run (tensorflow/keras absent here); the operators are
 pinned against the float64 oracle and torch-CPU vectors, the assembled network against a plain
@@ -162,6 +163,45 @@ class Conv3DModel:
                 out.append((e * e).mean())
         return out
 
+    FUSED_MAX_BATCH = 64        # wm_mse_metrics_f32 keeps a batch column in registers
+
+    def _fused_targets(self, pred, y):
+        """The targets as the (B, P) matrix wm_mse_metrics_f32 takes plus its broadcast flag, or
+        None for shapes that kernel does not cover (then the tensor expressions above are used)."""
+        B, P = pred.shape
+        if B > self.FUSED_MAX_BATCH:
+            return None
+        if y.dim() == 3 and self.broadcast_targets:
+            if y.shape[0] != B or y.shape[1] != 1 or y.shape[2] != P:
+                return None
+            return y.reshape(B, P), True
+        if y.numel() != B * P:
+            return None
+        return y.reshape(B, P), False
+
+    def _loss_stats(self, pred, y, want_grad):
+        """[loss, *metrics] as ONE small device tensor and d loss / d pred (or None): one kernel pass
+        (ops.mse_metrics) instead of ~20 element-wise launches over the (B, B, P) differences."""
+        ft = self._fused_targets(pred, y)
+        if ft is not None:
+            out3, grad = ops.mse_metrics(pred.detach(), ft[0], ft[1], eps=_MSLE_EPS,
+                                         want_grad=want_grad)
+            pick = [0] + [{"mae": 1, "msle": 2}[k] for k in self._metric_keys]
+            # (no list indexing: that builds its index tensor on the host, which a graph capture
+            # does not allow)
+            stats = out3[:len(pick)] if pick == [0, 1, 2][:len(pick)] else \
+                torch.stack([out3[k] for k in pick])
+            return stats, grad
+        if want_grad:
+            p = pred.detach().requires_grad_(True)
+            loss = self.loss_fn(p, y)
+            (grad,) = torch.autograd.grad(loss, p)
+        else:
+            loss, grad = self.loss_fn(pred.detach(), y), None
+        with torch.no_grad():
+            stats = torch.stack([loss.detach()] + self._metric_tensors(pred.detach(), y))
+        return stats, grad
+
     def _batch_metrics(self, pred, y):
         return {k: float(v) for k, v in zip(self._metric_keys, self._metric_tensors(pred, y))}
 
@@ -173,13 +213,10 @@ class Conv3DModel:
         y = self._targets(y)
         self.optimizer.zero_grad(set_to_none=True)
         pred = self.forward(self._to_dev(x1), self._to_dev(x2))
-        loss = self.loss_fn(pred, y)
-        loss.backward()
+        stats, grad = self._loss_stats(pred, y, True)
+        pred.backward(grad)
         self.optimizer.step()
-        logs = {"loss": float(loss.detach())}
-        with torch.no_grad():
-            logs.update(self._batch_metrics(pred.detach(), y))
-        return logs
+        return dict(zip(["loss"] + list(self._metric_keys), stats.tolist()))
 
     # ------------------------------------------------------------------ HIP graph replay
     def graphed_train_step(self, data):
@@ -198,12 +235,10 @@ class Conv3DModel:
 
             def body():
                 pred = self.forward(g["x1"], g["x2"])
-                loss = self.loss_fn(pred, g["y"])
-                loss.backward()
-                self.optimizer.step()
                 # loss and metrics leave the graph as ONE small tensor: one host read per step
-                with torch.no_grad():
-                    stats = torch.stack([loss.detach()] + self._metric_tensors(pred.detach(), g["y"]))
+                stats, grad = self._loss_stats(pred, g["y"], True)
+                pred.backward(grad)
+                self.optimizer.step()
                 return stats, pred.detach()
 
             # warm up on a side stream (optimizer state, lazily initialised library state), with
@@ -250,8 +285,8 @@ class Conv3DModel:
         y = self._targets(y)
         with torch.no_grad():
             pred = self.forward(self._to_dev(x1), self._to_dev(x2))
-            logs = {"loss": float(self.loss_fn(pred, y))}
-            logs.update(self._batch_metrics(pred, y))
+            stats, _ = self._loss_stats(pred, y, False)
+            logs = dict(zip(["loss"] + list(self._metric_keys), stats.tolist()))
         return logs
 
     def fit(self, x=None, y=None, batch_size=None, epochs=1, verbose=1, callbacks=None,

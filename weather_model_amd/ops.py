@@ -568,6 +568,30 @@ def gather_cubes(vol, cube, d_mid, d_end, rows, origins=None, walk=None, separat
     return (x1, x2, Yo) if separate else (Xo, Yo)
 
 
+def mse_metrics(pred, y, broadcast, eps=1e-7, want_grad=True):
+    """Mean squared error, mean absolute error, mean squared logarithmic error and d(mse)/d(pred)
+    of predictions (B, P) against targets (B, P) in one pass (``wm_mse_metrics_f32``); with
+    ``broadcast`` every prediction is scored against every target of the batch (what the
+    reference's (B, 1, P) targets do, convolution.py:137,214).  Returns (out3, grad): a float32
+    device tensor [mse, mae, msle] and the gradient (or None).  B <= 64."""
+    pred = _req(pred, "pred")
+    y = _req(y, "targets")
+    if pred.dim() != 2 or y.shape != pred.shape:
+        raise ValueError(f"pred and targets must both be (B, P), got {tuple(pred.shape)} and "
+                         f"{tuple(y.shape)}")
+    B, P = pred.shape
+    L = _lib.lib()
+    with torch.cuda.device(pred.device):
+        ws = torch.empty((max(L.wm_mse_metrics_workspace_bytes(P), 8),), device=pred.device,
+                         dtype=torch.uint8)
+        out3 = torch.empty((3,), device=pred.device, dtype=torch.float32)
+        grad = torch.empty_like(pred) if want_grad else None
+        _lib.check(L.wm_mse_metrics_f32(pred.data_ptr(), y.data_ptr(), B, P, 1 if broadcast else 0,
+                                        float(eps), 0 if grad is None else grad.data_ptr(),
+                                        out3.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
+    return out3, grad
+
+
 # --------------------------------------------------------------------------- synthetic data
 
 def synth_uniform(shape, seed, lo=0.0, hi=1.0, offset=0, device="cuda"):
