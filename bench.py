@@ -876,8 +876,13 @@ def run_conv3d_model(steps, warmup, batch=16):
         m.graphed_train_step((x1, x2, y))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        logs = m.graphed_train_step((x1, x2, y))
+    pending = None
+    for _ in range(steps):                      # as Conv3DModel.fit drives it: logs read one step late
+        issued = m.graphed_train_step((x1, x2, y), defer=True)
+        if pending is not None:
+            logs = pending.result()
+        pending = issued
+    logs = pending.result()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     # 2 branches x (layer 1: 16*14^3 outputs x 32 x 343, layer 2: 16*3*3*10 x 64 x 2000) MACs forward,
@@ -887,7 +892,8 @@ def run_conv3d_model(steps, warmup, batch=16):
     flops = 2 * conv + 2 * 2.0 * batch * 90 * 64 * 2000 + 3 * 2.0 * batch * (640 * 640 + 640 * 8000)
     return {"value": batch / dt, "unit": "samples/s", "ms_per_step": dt * 1e3, "loss": logs["loss"],
             "config": {"workload": f"Conv3D interpolation model, input (1,20,20,20), batch {batch}, "
-                                   "fit step (HIP-graph replay)"},
+                                   "fit step (HIP-graph replay, every step's loss and metrics "
+                                   "read back, one step late as in fit())"},
             "roofline": {"bound": "mfma", "achieved": flops / dt / 1e12, "peak": MFMA_F32_PEAK_TF,
                          "unit": "TFLOP/s", "frac": flops / dt / 1e12 / MFMA_F32_PEAK_TF,
                          "traffic": None, "kernel": "conv3d split-K / small-volume kernels (gather-"

@@ -129,6 +129,40 @@ def test_graphed_train_step_matches_eager():
         assert relinf(b.params[k].detach().cpu().numpy(), a.params[k].detach().cpu().numpy()) < 1e-5, k
 
 
+def test_deferred_logs_are_the_steps_own_logs():
+    """graphed_train_step(defer=True): logs read one step late (as fit() does) are bit for bit the
+    logs of an immediate read, also when the next replay has already overwritten the graph's
+    statistics tensor, and fit() on the deferred path gives the immediate path's history."""
+    from weather_model_amd.dropin._conv3d_model import Conv3DModel
+    a = Conv3DModel((1, 20, 20, 20), seed=9)
+    b = Conv3DModel((1, 20, 20, 20), seed=9)
+    metrics = ["mean_absolute_error", "mean_squared_logarithmic_error"]
+    a.compile(loss="mean_squared_error", metrics=metrics)
+    b.compile(loss="mean_squared_error", metrics=metrics)
+    rng = np.random.default_rng(3)
+    batches = [(rng.uniform(size=(4, 1, 20, 20, 20)).astype(np.float32),
+                rng.uniform(size=(4, 1, 20, 20, 20)).astype(np.float32),
+                rng.uniform(size=(4, 1, 8000)).astype(np.float32)) for _ in range(5)]
+    la = [a.graphed_train_step(bt) for bt in batches]
+    pend = [b.graphed_train_step(bt, defer=True) for bt in batches[:3]]     # three outstanding
+    lb = [p.result() for p in pend]
+    for bt in batches[3:]:
+        lb.append(b.graphed_train_step(bt, defer=True).result())
+    assert la == lb
+    c = Conv3DModel((1, 20, 20, 20), seed=9)
+    d = Conv3DModel((1, 20, 20, 20), seed=9)
+    c.compile(loss="mean_squared_error", metrics=metrics)
+    d.compile(loss="mean_squared_error", metrics=metrics)
+    it = lambda: iter(batches)                                              # noqa: E731
+    hc = c.fit(it(), epochs=1, steps_per_epoch=5, verbose=0)
+    sums = {}
+    for bt in batches:
+        for k, v in d.graphed_train_step(bt).items():
+            sums[k] = sums.get(k, 0.0) + v
+    for k in sums:
+        assert hc.history[k][0] == pytest.approx(sums[k] / 5, rel=1e-12)
+
+
 def test_graphed_step_keeps_one_graph_per_batch_shape():
     """Alternating batch sizes (the short last batch of an epoch) replay their own graphs and stay
     on the eager trajectory."""

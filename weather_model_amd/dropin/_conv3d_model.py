@@ -37,6 +37,21 @@ def _glorot(shape, fan_in, fan_out, gen, device):
     return t.to(device).requires_grad_(True)
 
 
+class PendingLogs:
+    """Logs of a deferred ``graphed_train_step``: a pinned host copy of the step's [loss, *metrics]
+    and the event that marks it complete.  Slots are reused round-robin (``Conv3DModel.LOG_RING``):
+    read a step's logs before that many further steps have been issued."""
+
+    def __init__(self, n):
+        self.host = torch.empty((n,), dtype=torch.float32, pin_memory=True)
+        self.event = torch.cuda.Event()
+        self.names = []
+
+    def result(self):
+        self.event.synchronize()
+        return dict(zip(self.names, self.host.tolist()))
+
+
 class Conv3DModel:
     """``create_model(input_shape)`` of convolution.py; ``input_shape = (n_vars, Z, Y, X)``."""
 
@@ -164,6 +179,7 @@ class Conv3DModel:
         return out
 
     FUSED_MAX_BATCH = 64        # wm_mse_metrics_f32 keeps a batch column in registers
+    LOG_RING = 4                # deferred logs that may be outstanding at once
 
     def _fused_targets(self, pred, y):
         """The targets as the (B, P) matrix wm_mse_metrics_f32 takes plus its broadcast flag, or
@@ -219,11 +235,15 @@ class Conv3DModel:
         return dict(zip(["loss"] + list(self._metric_keys), stats.tolist()))
 
     # ------------------------------------------------------------------ HIP graph replay
-    def graphed_train_step(self, data):
+    def graphed_train_step(self, data, defer=False):
         """``train_step`` replayed from a HIP graph: the ~60 launches of one step (two conv branches
         forward and backward, pools, the dense GEMMs, Adam) are captured once per batch shape and
         replayed with one host call -- the step is launch-bound otherwise (2.1 ms of which 1.2 ms
-        is GPU time at batch 16).  Returns the same logs as ``train_step`` (loss, mae, msle)."""
+        is GPU time at batch 16).  Returns the same logs as ``train_step`` (loss, mae, msle).
+        With ``defer`` the logs come back as a ``PendingLogs`` whose ``result()`` waits for the
+        step: the caller can stage and launch the next step first (``fit`` reads every step's
+        logs one step late), so the host work of a step -- ~90 us of staging during which the GPU
+        was idle -- overlaps the previous replay."""
         if self.optimizer is None:
             raise RuntimeError("compile the model before training")
         x1, x2, y = (self._to_dev(data[0]), self._to_dev(data[1]), self._targets(data[2]))
@@ -274,11 +294,23 @@ class Conv3DModel:
             graphs[key] = g
         for p, gr in zip(self.params.values(), g["grads"]):
             p.grad = gr                                  # an eager step in between may rebind them
-        g["x1"].copy_(x1)
-        g["x2"].copy_(x2)
-        g["y"].copy_(y)
+        torch._foreach_copy_([g["x1"], g["x2"], g["y"]], [x1, x2, y])     # one launch, not three
         g["graph"].replay()
-        return dict(zip(["loss"] + list(self._metric_keys), g["stats"].tolist()))
+        names = ["loss"] + list(self._metric_keys)
+        if not defer:
+            return dict(zip(names, g["stats"].tolist()))
+        # the next replay overwrites g["stats"]: copy it out in stream order, into pinned memory
+        ring = self.__dict__.setdefault("_log_ring", [])
+        if not ring:
+            ring.extend(PendingLogs(len(names)) for _ in range(self.LOG_RING))
+        self._log_next = (self.__dict__.get("_log_next", -1) + 1) % self.LOG_RING
+        slot = ring[self._log_next]
+        if slot.host.numel() != len(names):
+            slot.host = torch.empty((len(names),), dtype=torch.float32, pin_memory=True)
+        slot.names = names
+        slot.host.copy_(g["stats"], non_blocking=True)
+        slot.event.record()
+        return slot
 
     def test_step(self, data):
         x1, x2, y = data
@@ -307,11 +339,25 @@ class Conv3DModel:
             sums, count = {}, 0
             batches = (next(it) for _ in range(int(steps_per_epoch))) if it is not None \
                 else _batches(source, steps_per_epoch)
-            for batch in batches:
-                step = self.graphed_train_step if use_graph else self.train_step
-                for k, v in step(batch).items():
+            pending = None
+
+            def add(step_logs):
+                for k, v in step_logs.items():
                     sums[k] = sums.get(k, 0.0) + v
+
+            for batch in batches:
+                if use_graph:
+                    # issue step i, then read the logs of step i-1: the host staging of a step
+                    # runs while the previous replay is still on the GPU
+                    issued = self.graphed_train_step(batch, defer=True)
+                    if pending is not None:
+                        add(pending.result())
+                    pending = issued
+                else:
+                    add(self.train_step(batch))
                 count += 1
+            if pending is not None:
+                add(pending.result())
             logs = {k: v / max(count, 1) for k, v in sums.items()}
             if validation_data is not None:
                 vs, vc = {}, 0
