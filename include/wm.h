@@ -277,6 +277,22 @@ int wm_gather_cubes_strided_f32(const float *vol, int files, int nvars, int Z, i
                                 float *x1out, float *x2out, int64_t xstride, float *yout,
                                 void *stream);
 
+/* The Dense layers of the Conv3D model (convolution.py:175-176: Dense(flat, relu), Dense(prod(
+ * input_shape))) and their gradients, replacing keras.layers.Dense / its autodiff for the batch
+ * sizes the reference trains with.  x is (M, K), W is (N, K) = (units, inputs), b is (N) or NULL,
+ * y is (M, N); relu != 0 applies max(., 0).  N % 4 == 0 and K % 4 == 0 (WM_ERR_UNSUPPORTED
+ * otherwise), all tensors 16-byte aligned.
+ * wm_dense_bwd_f32: gx (M, K) = gy W, masked where mask_below <= 0 when mask_below != NULL (the
+ * post-ReLU activation that fed this layer, i.e. x itself: the ReLU backward of the layer below
+ * fused into the store); gW (N, K) = gy^T x; gb (N) = column sums of gy.  gx or gW (with gb) may be
+ * NULL to skip that part.  The workspace holds the split partial sums of gx. */
+int wm_dense_fwd_f32(const float *x, const float *W, const float *b, float *y, int M, int N, int K,
+                     int relu, void *stream);
+size_t wm_dense_bwd_workspace_bytes(int M, int N, int K);
+int wm_dense_bwd_f32(const float *x, const float *W, const float *gy, const float *mask_below,
+                     float *gx, float *gW, float *gb, void *workspace, size_t workspace_bytes,
+                     int M, int N, int K, void *stream);
+
 /* Loss, metrics and loss gradient of the Conv3D model's train step in one pass, replacing
  * keras' compile(loss='mean_squared_error', metrics=['mean_absolute_error',
  * 'mean_squared_logarithmic_error']) as fit() evaluates it (convolution.py:176-180, train_step
@@ -284,7 +300,7 @@ int wm_gather_cubes_strided_f32(const float *vol, int files, int nvars, int Z, i
  * target of the batch -- what the reference's (B, 1, P) targets do to the (B, P) predictions
  * (SURVEY.md 2b); broadcast == 0 pairs row i with row i.  out3 = {mean (y-p)^2, mean |y-p|,
  * mean (log1p(max(p,eps)) - log1p(max(y,eps)))^2} (device memory, 3 floats); grad (may be NULL) is
- * d out3[0] / d pred, shape (B, P).  B <= 64.  Sums are float64 in a fixed order. */
+ * d out3[0] / d pred, shape (B, P).  B <= 4096.  Sums are float64 in a fixed order. */
 size_t wm_mse_metrics_workspace_bytes(int64_t P);
 int wm_mse_metrics_f32(const float *pred, const float *y, int B, int64_t P, int broadcast,
                        float eps, float *grad, float *out3, void *workspace,

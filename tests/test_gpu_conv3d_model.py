@@ -215,7 +215,7 @@ def test_data_generator_device_batches_bit_exact():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,P,broadcast", [(16, 8000, True), (5, 37, True), (33, 1000, True),
-                                           (64, 130, True), (16, 8000, False), (1, 3, True)])
+                                           (64, 130, True), (16, 8000, False), (1, 3, True), (200, 24, True)])
 def test_fused_loss_metrics_and_gradient(B, P, broadcast):
     """wm_mse_metrics_f32 against the tensor expressions of the model (keras' mean_squared_error
     on (B,1,P) targets, mae, msle with the epsilon clip) and autograd's gradient, in float64."""
@@ -238,4 +238,38 @@ def test_fused_loss_metrics_and_gradient(B, P, broadcast):
     again, _ = ops.mse_metrics(pred.cuda(), y.cuda(), broadcast, want_grad=False)
     assert torch.equal(again, out3)                               # fixed-order sums
     with pytest.raises(Exception, match="out of range"):
-        ops.mse_metrics(torch.zeros((65, 4), device="cuda"), torch.zeros((65, 4), device="cuda"), True)
+        ops.mse_metrics(torch.zeros((4097, 4), device="cuda"), torch.zeros((4097, 4), device="cuda"), True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,K,N", [(16, 640, 640), (16, 640, 8000), (4, 640, 8000), (5, 36, 20),
+                                   (33, 52, 100), (1, 4, 4)])
+def test_dense_layers_match_float64(M, K, N):
+    """wm_dense_fwd_f32 / wm_dense_bwd_f32 (and their autograd wrapper with the ReLU backward fused
+    into the consumer's gx store) against float64 torch on the CPU."""
+    from weather_model_amd import ops
+    gen = torch.Generator().manual_seed(M * 7 + N)
+    x = torch.rand((M, K), generator=gen) - 0.5
+    W1 = (torch.rand((K, K), generator=gen) - 0.5) * 0.2
+    b1 = torch.rand((K,), generator=gen) - 0.5
+    W2 = (torch.rand((N, K), generator=gen) - 0.5) * 0.2
+    b2 = torch.rand((N,), generator=gen) - 0.5
+    g = torch.rand((M, N), generator=gen) - 0.5
+    leaves = [t.cuda().requires_grad_(True) for t in (x, W1, b1, W2, b2)]
+    h = ops.dense(leaves[0], leaves[1], leaves[2], relu=True, relu_bwd_fused=True)
+    out = ops.dense(h, leaves[3], leaves[4], relu_input=True)
+    out.backward(g.cuda())
+    ref = [t.double().requires_grad_(True) for t in (x, W1, b1, W2, b2)]
+    hr = torch.relu(F.linear(ref[0], ref[1], ref[2]))
+    outr = F.linear(hr, ref[3], ref[4])
+    outr.backward(g.double())
+    assert relinf(out.detach().cpu().numpy(), outr.detach().numpy()) < 1e-5
+    for a, r, name in zip(leaves, ref, ("x", "W1", "b1", "W2", "b2")):
+        assert relinf(a.grad.cpu().numpy(), r.grad.numpy()) < 1e-5, name
+    # the stand-alone form: ReLU backward applied by the layer itself
+    l2 = [t.cuda().requires_grad_(True) for t in (x, W1, b1)]
+    ops.dense(l2[0], l2[1], l2[2], relu=True).backward(torch.ones((M, K), device="cuda"))
+    r2 = [t.double().requires_grad_(True) for t in (x, W1, b1)]
+    torch.relu(F.linear(r2[0], r2[1], r2[2])).sum().backward()
+    for a, r in zip(l2, r2):
+        assert relinf(a.grad.cpu().numpy(), r.grad.numpy()) < 1e-5

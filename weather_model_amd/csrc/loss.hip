@@ -8,18 +8,19 @@
 //   msle = mean (log1p(max(p_i, eps)) - log1p(max(y_j, eps)))^2,
 //   grad[i] = d loss / d p_i = 2 / (pairs * P) * sum_j (p_i - y_j)
 // Framework glue takes ~20 element-wise launches over the (B, B, P) differences for this (90 us of a
-// 560 us step at batch 16); here a thread owns one column p, keeps the B targets of the column and
-// their logs in registers and walks the B predictions.  Sums are float32 per thread (<= B*B terms),
-// float64 from there on, combined in a fixed order (bitwise reproducible).
+// 560 us step at batch 16); here one pass.  Sums are float32 per thread (<= B terms), float64 from
+// there on, combined in a fixed order (bitwise reproducible).
 #include "common.h"
 
 namespace {
 
 constexpr int BLOCK = 256;
-constexpr int MAXB = 64;          // batch rows held in registers per column
+constexpr int MAXB = 4096;        // float32 pair sums per thread stay short
 
-// partial: [3][gridDim.x] float64
-template <int NB>   // NB >= B, a power of two: the register arrays are fully unrolled
+// One thread per prediction (i, p): it walks the targets y[j][p] it is scored against (all B rows
+// with `broadcast`, row i otherwise) -- the p of a wave are consecutive, so every load is
+// coalesced, and B * P threads fill the chip where one thread per column (P = 8000: 125 waves)
+// took 22 us on its serial chain of loads and logs.  partial: [3][gridDim.x] float64.
 __global__ __launch_bounds__(BLOCK) void mse_metrics_kernel(const float *__restrict__ pred,
                                                             const float *__restrict__ y, int B,
                                                             long long P, int broadcast, float eps,
@@ -28,44 +29,24 @@ __global__ __launch_bounds__(BLOCK) void mse_metrics_kernel(const float *__restr
 {
     __shared__ double red[BLOCK / 64][3];
     double se = 0.0, ae = 0.0, le = 0.0;
-    for (long long p = (long long)blockIdx.x * BLOCK + threadIdx.x; p < P;
-         p += (long long)gridDim.x * BLOCK) {
-        float s2 = 0.0f, s1 = 0.0f, sl = 0.0f;
-        if (broadcast) {
-            float yv[NB], ly[NB];
-            float ysum = 0.0f;
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                yv[j] = j < B ? y[(long long)j * P + p] : 0.0f;
-                ly[j] = log1pf(fmaxf(yv[j], eps));
-                ysum += yv[j];
-            }
-#pragma unroll 1
-            for (int i = 0; i < B; ++i) {
-                const float pv = pred[(long long)i * P + p];
-                const float lp = log1pf(fmaxf(pv, eps));
-#pragma unroll
-                for (int j = 0; j < NB; ++j) {
-                    const float d = yv[j] - pv, e = lp - ly[j];
-                    const bool on = j < B;
-                    s2 += on ? d * d : 0.0f;
-                    s1 += on ? fabsf(d) : 0.0f;
-                    sl += on ? e * e : 0.0f;
-                }
-                if (grad) grad[(long long)i * P + p] = gscale * ((float)B * pv - ysum);
-            }
-        } else {
-#pragma unroll 1
-            for (int i = 0; i < B; ++i) {
-                const float pv = pred[(long long)i * P + p], yi = y[(long long)i * P + p];
-                const float d = yi - pv;
-                const float e = log1pf(fmaxf(pv, eps)) - log1pf(fmaxf(yi, eps));
-                s2 += d * d;
-                s1 += fabsf(d);
-                sl += e * e;
-                if (grad) grad[(long long)i * P + p] = gscale * (pv - yi);
-            }
+    const long long total = (long long)B * P;
+    for (long long e = (long long)blockIdx.x * BLOCK + threadIdx.x; e < total;
+         e += (long long)gridDim.x * BLOCK) {
+        const long long i = e / P, p = e - i * P;
+        const float pv = pred[e];
+        const float lp = log1pf(fmaxf(pv, eps));
+        float s2 = 0.0f, s1 = 0.0f, sl = 0.0f, ysum = 0.0f;
+        const int j0 = broadcast ? 0 : (int)i, j1 = broadcast ? B : (int)i + 1;
+#pragma unroll 8
+        for (int j = j0; j < j1; ++j) {
+            const float yv = y[(long long)j * P + p];
+            const float d = yv - pv, q = lp - log1pf(fmaxf(yv, eps));
+            s2 = fmaf(d, d, s2);
+            s1 += fabsf(d);
+            sl = fmaf(q, q, sl);
+            ysum += yv;
         }
+        if (grad) grad[e] = gscale * ((float)(j1 - j0) * pv - ysum);
         se += (double)s2;
         ae += (double)s1;
         le += (double)sl;
@@ -100,9 +81,9 @@ __global__ __launch_bounds__(64) void mse_metrics_finalize_kernel(const double *
     if (threadIdx.x == 0) out[k] = (float)(s * inv_count);
 }
 
-int loss_grid(long long P)
+int loss_grid(long long BP)
 {
-    long long g = (P + BLOCK - 1) / BLOCK;
+    long long g = (BP + BLOCK - 1) / BLOCK;
     const long long cap = (long long)wm_num_cus() * 4;
     if (g > cap) g = cap;
     if (g < 1) g = 1;
@@ -113,8 +94,9 @@ int loss_grid(long long P)
 
 extern "C" size_t wm_mse_metrics_workspace_bytes(int64_t P)
 {
+    // upper bound for any batch size: the grid is capped at 4 workgroups per CU
     if (P <= 0 || wm_num_cus() <= 0) return 0;
-    return wm_align_up((size_t)loss_grid(P) * 3 * sizeof(double), 256);
+    return wm_align_up((size_t)wm_num_cus() * 4 * 3 * sizeof(double), 256);
 }
 
 extern "C" int wm_mse_metrics_f32(const float *pred, const float *y, int B, int64_t P,
@@ -132,17 +114,11 @@ extern "C" int wm_mse_metrics_f32(const float *pred, const float *y, int B, int6
     const double pairs = broadcast ? (double)B * B : (double)B;
     const double count = pairs * (double)P;
     const float gscale = (float)(2.0 / count);
-    const int grid = loss_grid(P);
+    const int grid = loss_grid((long long)B * P);
     hipStream_t st = (hipStream_t)stream;
     double *partial = (double *)workspace;
-#define WM_LOSS_LAUNCH(NB)                                                                     \
-    hipLaunchKernelGGL(mse_metrics_kernel<NB>, dim3(grid), dim3(BLOCK), 0, st, pred, y, B,      \
-                       (long long)P, broadcast, eps, gscale, grad, partial)
-    if (B <= 8) WM_LOSS_LAUNCH(8);
-    else if (B <= 16) WM_LOSS_LAUNCH(16);
-    else if (B <= 32) WM_LOSS_LAUNCH(32);
-    else WM_LOSS_LAUNCH(64);
-#undef WM_LOSS_LAUNCH
+    hipLaunchKernelGGL(mse_metrics_kernel, dim3(grid), dim3(BLOCK), 0, st, pred, y, B, (long long)P,
+                       broadcast, eps, gscale, grad, partial);
     WM_LAUNCH_CHECK("mse_metrics_kernel");
     hipLaunchKernelGGL(mse_metrics_finalize_kernel, dim3(3), dim3(64), 0, st, partial, grid,
                        1.0 / count, out3);

@@ -11,8 +11,10 @@ That is reproduced (``pool_channels_last=True``); ``False`` gives the presumably
 
 Convolutions, pools and their gradients are the hand-written kernels (``ops.conv3d``,
 ``ops.maxpool3d``), loss + metrics + loss gradient are one hand-written pass (``ops.mse_metrics``);
-the two Dense layers are plain library GEMMs (``torch.nn.functional.linear`` = rocBLAS/hipBLASLt)
-and Adam is ``torch.optim.Adam`` with Keras' epsilon.  No CPU path.
+the two Dense layers are the skinny MFMA products of ``dense.hip`` (``ops.dense``: bias + ReLU in the
+forward store, dense1's ReLU backward in the output layer's input-gradient store; widths that are
+not multiples of 4 floats go to ``torch.nn.functional.linear``) and Adam is ``torch.optim.Adam``
+with Keras' epsilon.  No CPU path.
 
 Parity: unpinned against the reference's own run (tensorflow/keras absent here); the operators are
 pinned against the float64 oracle and torch-CPU vectors, the assembled network against a plain
@@ -111,8 +113,15 @@ class Conv3DModel:
 
     def forward(self, x1, x2):
         h = torch.cat((self._branch(x1, "1"), self._branch(x2, "2")), dim=1)
-        h = F.relu(F.linear(h, self.params["dense1/kernel"], self.params["dense1/bias"]))
-        return F.linear(h, self.params["output/kernel"], self.params["output/bias"])
+        p = self.params
+        if ops.dense_supported(self.flat, self.flat) and ops.dense_supported(self.flat, self.out_dim):
+            # hand-written skinny products; dense1's ReLU backward is applied in the output
+            # layer's input-gradient store
+            h = ops.dense(h, p["dense1/kernel"], p["dense1/bias"], relu=True, relu_bwd_fused=True)
+            return ops.dense(h, p["output/kernel"], p["output/bias"], relu_input=True)
+        # widths that are not multiples of 4 floats: plain library GEMMs
+        h = F.relu(F.linear(h, p["dense1/kernel"], p["dense1/bias"]))
+        return F.linear(h, p["output/kernel"], p["output/bias"])
 
     def _to_dev(self, a):
         t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a, np.float32))
@@ -178,7 +187,7 @@ class Conv3DModel:
                 out.append((e * e).mean())
         return out
 
-    FUSED_MAX_BATCH = 64        # wm_mse_metrics_f32 keeps a batch column in registers
+    FUSED_MAX_BATCH = 4096      # wm_mse_metrics_f32's limit (float32 sums of B terms per thread)
     LOG_RING = 4                # deferred logs that may be outstanding at once
 
     def _fused_targets(self, pred, y):

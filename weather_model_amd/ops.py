@@ -568,12 +568,87 @@ def gather_cubes(vol, cube, d_mid, d_end, rows, origins=None, walk=None, separat
     return (x1, x2, Yo) if separate else (Xo, Yo)
 
 
+def dense_supported(in_features, out_features):
+    """Shapes ``wm_dense_*`` take (16-byte rows)."""
+    return in_features % 4 == 0 and out_features % 4 == 0
+
+
+def dense_forward(x, weight, bias=None, relu=False):
+    """act(x @ weight.T + bias) for x (M, K), weight (N, K) (``wm_dense_fwd_f32``)."""
+    x, weight = _req(x, "input"), _req(weight, "weight")
+    if x.dim() != 2 or weight.dim() != 2 or x.shape[1] != weight.shape[1]:
+        raise ValueError(f"dense expects (M, K) and (N, K), got {tuple(x.shape)}, {tuple(weight.shape)}")
+    M, K = x.shape
+    N = weight.shape[0]
+    b = None if bias is None else _req(bias, "bias")
+    y = torch.empty((M, N), device=x.device, dtype=torch.float32)
+    if M == 0:
+        return y
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().wm_dense_fwd_f32(x.data_ptr(), weight.data_ptr(),
+                                               0 if b is None else b.data_ptr(), y.data_ptr(), M, N,
+                                               K, 1 if relu else 0, _stream()))
+    return y
+
+
+def dense_backward(x, weight, gy, mask_below=None, need_gx=True, need_gw=True):
+    """(gx, gW, gb) of ``dense_forward`` given the gradient gy of its PRE-activation output;
+    ``mask_below`` (the post-ReLU activation that is this layer's input) zeroes gx where it is
+    not positive (``wm_dense_bwd_f32``)."""
+    x, weight, gy = _req(x, "input"), _req(weight, "weight"), _req(gy, "grad_output")
+    M, K = x.shape
+    N = weight.shape[0]
+    L = _lib.lib()
+    gx = torch.empty((M, K), device=x.device, dtype=torch.float32) if need_gx else None
+    gw = torch.empty((N, K), device=x.device, dtype=torch.float32) if need_gw else None
+    gb = torch.empty((N,), device=x.device, dtype=torch.float32) if need_gw else None
+    mb = None if mask_below is None else _req(mask_below, "mask")
+    with torch.cuda.device(x.device):
+        ws = torch.empty((max(L.wm_dense_bwd_workspace_bytes(M, N, K), 16),), device=x.device,
+                         dtype=torch.uint8)
+        _lib.check(L.wm_dense_bwd_f32(
+            x.data_ptr(), weight.data_ptr(), gy.data_ptr(), 0 if mb is None else mb.data_ptr(),
+            0 if gx is None else gx.data_ptr(), 0 if gw is None else gw.data_ptr(),
+            0 if gb is None else gb.data_ptr(), ws.data_ptr(), ws.numel(), M, N, K, _stream()))
+    return gx, gw, gb
+
+
+class DenseFunction(torch.autograd.Function):
+    """y = act(x W^T + b).  ``relu_input``: the input x is a post-ReLU activation and this layer
+    applies that ReLU's backward in its gx store.  ``relu_bwd_fused``: this layer's own ReLU
+    backward is applied by its consumer (a DenseFunction with ``relu_input``), so the incoming
+    gradient is already that of the pre-activation."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu, relu_input, relu_bwd_fused):
+        y = dense_forward(x, weight, bias, relu)
+        own_mask = relu and not relu_bwd_fused
+        ctx.save_for_backward(x, weight, y if own_mask else None)
+        ctx.own_mask, ctx.relu_input, ctx.has_bias = own_mask, relu_input, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, y = ctx.saved_tensors
+        gy = gy.contiguous()
+        if ctx.own_mask:
+            gy = relu_mask(gy, y)                     # stand-alone mask (no fusing consumer)
+        gx, gw, gb = dense_backward(x, weight, gy, x if ctx.relu_input else None,
+                                    need_gx=ctx.needs_input_grad[0],
+                                    need_gw=ctx.needs_input_grad[1])
+        return gx, gw, (gb if ctx.has_bias else None), None, None, None
+
+
+def dense(x, weight, bias=None, relu=False, relu_input=False, relu_bwd_fused=False):
+    return DenseFunction.apply(x, weight, bias, relu, relu_input, relu_bwd_fused)
+
+
 def mse_metrics(pred, y, broadcast, eps=1e-7, want_grad=True):
     """Mean squared error, mean absolute error, mean squared logarithmic error and d(mse)/d(pred)
     of predictions (B, P) against targets (B, P) in one pass (``wm_mse_metrics_f32``); with
     ``broadcast`` every prediction is scored against every target of the batch (what the
     reference's (B, 1, P) targets do, convolution.py:137,214).  Returns (out3, grad): a float32
-    device tensor [mse, mae, msle] and the gradient (or None).  B <= 64."""
+    device tensor [mse, mae, msle] and the gradient (or None).  B <= 4096."""
     pred = _req(pred, "pred")
     y = _req(y, "targets")
     if pred.dim() != 2 or y.shape != pred.shape:
