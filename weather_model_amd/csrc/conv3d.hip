@@ -1885,12 +1885,14 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 // slab x[b, :, od..od+kD-1, :, :] and gy[b, :, od, :, :] are copied once into LDS, coalesced, and
 // both MFMA operands are LDS reads (B at tap offset + position offset, both from tiny tables).
 // grid = (B*OD planes, groups of WAVES*KTW tap tiles); a wave keeps KTW tap tiles x OT channel
-// tiles in registers over the plane and stores them as float64 to the plane's partial slab;
-// conv3d_reduce_kernel sums the B*OD slabs in a fixed order.
+// tiles in registers over the plane and stores them to the plane's partial slab -- as float32: the
+// sums ARE float32 MFMA accumulators of one plane, so a float64 slab holds nothing more and costs
+// twice the traffic (layer 2 of the reference: 49 MB written and read back per call);
+// conv3d_reduce16_kernel sums the B*OD slabs in float64 in a fixed order.
 template <int OT, int KTW>
 __global__ __launch_bounds__(BLOCK) void conv3d_bwd_wb_vol_kernel(const float *__restrict__ x,
                                                                   const float *__restrict__ gy,
-                                                                  double *__restrict__ partial,
+                                                                  float *__restrict__ partial,
                                                                   Dims3 d, int K)
 {
     extern __shared__ __align__(16) float smem[];
@@ -1951,7 +1953,7 @@ __global__ __launch_bounds__(BLOCK) void conv3d_bwd_wb_vol_kernel(const float *_
             for (int t = 0; t < OT; ++t) acc[q][t] = mma(a[t], bq[q], acc[q][t]);
     }
     const int nw = d.Cout * K, nent = nw + d.Cout;
-    double *dst = partial + (size_t)plane * nent;
+    float *dst = partial + (size_t)plane * nent;
 #pragma unroll
     for (int q = 0; q < KTW; ++q) {
         const int k_b = (((int)blockIdx.y * KTW + q) * WAVES + wave) * 16 + j;
@@ -1961,8 +1963,8 @@ __global__ __launch_bounds__(BLOCK) void conv3d_bwd_wb_vol_kernel(const float *_
             for (int r = 0; r < 4; ++r) {
                 const int o = t * 16 + 4 * g + r;
                 if (o < d.Cout) {
-                    if (k_b < K) dst[(size_t)o * K + k_b] = (double)acc[q][t][r];
-                    else if (k_b == K) dst[nw + o] = (double)acc[q][t][r];
+                    if (k_b < K) dst[(size_t)o * K + k_b] = acc[q][t][r];
+                    else if (k_b == K) dst[nw + o] = acc[q][t][r];
                 }
             }
     }
@@ -1983,7 +1985,7 @@ __global__ __launch_bounds__(64) void conv3d_reduce_kernel(const double *__restr
 
 // conv3d_reduce_kernel for many slabs: 64 entries x 16 slab groups per workgroup, group partials
 // combined through LDS in a fixed order
-__global__ __launch_bounds__(1024) void conv3d_reduce16_kernel(const double *__restrict__ partial,
+__global__ __launch_bounds__(1024) void conv3d_reduce16_kernel(const float *__restrict__ partial,
                                                                int nparts, int nent, int nw,
                                                                float *__restrict__ gw,
                                                                float *__restrict__ gb)
@@ -1993,7 +1995,7 @@ __global__ __launch_bounds__(1024) void conv3d_reduce16_kernel(const double *__r
     const int e = blockIdx.x * 64 + le;
     double s = 0.0;
     if (e < nent)
-        for (int p = grp; p < nparts; p += 16) s += partial[(size_t)p * nent + e];
+        for (int p = grp; p < nparts; p += 16) s += (double)partial[(size_t)p * nent + e];
     part[grp][le] = s;
     __syncthreads();
     if (grp == 0 && e < nent) {
@@ -2116,7 +2118,7 @@ bool wb_vol_plan(int B, int Cin, int D, int H, int W, int Cout, int kD, int kH, 
     return true;
 }
 
-typedef void (*wb_vol_fn)(const float *, const float *, double *, Dims3, int);
+typedef void (*wb_vol_fn)(const float *, const float *, float *, Dims3, int);
 wb_vol_fn wb_vol_kernel(int otiles, int ktw)
 {
 #define WBV_K(OT_)                                                                \
@@ -2581,10 +2583,10 @@ extern "C" int wm_conv3d_bwd_wb_f32(const float *x, const float *gy, float *gw, 
     if (wb_vol_plan(B, Cin, D, H, W, Cout, kD, kH, kW, &vktw, &vgroups, &vlds)) {
         const int planes = B * d.OD;
         hipLaunchKernelGGL(wb_vol_kernel(otiles, vktw), dim3(planes, vgroups), dim3(BLOCK), vlds, st,
-                           x, gy, (double *)workspace, d, K);
+                           x, gy, (float *)workspace, d, K);
         WM_LAUNCH_CHECK("conv3d_bwd_wb_vol_kernel");
         hipLaunchKernelGGL(conv3d_reduce16_kernel, dim3((nent + 63) / 64), dim3(1024), 0, st,
-                           (const double *)workspace, planes, nent, nw, gw, gb);
+                           (const float *)workspace, planes, nent, nw, gw, gb);
         WM_LAUNCH_CHECK("conv3d_reduce16_kernel");
         return WM_OK;
     }
