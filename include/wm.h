@@ -157,7 +157,12 @@ int wm_gram_f32(const float *X, const float *Y, int64_t n, int F, int P, double 
 /* Solves the normal equations held in acc for the affine map the reference's model spans:
  *   beta is (F+1) x P row-major float64, row F is the intercept (0 if fit_intercept == 0).
  * ridge is added to the diagonal of the (centred) X'X.  *status (device int, may be NULL) is set
- * to 0, or to 1 if the system was not positive definite (beta is then left NaN). */
+ * to 0, or to 1 if the system was not positive definite (beta is then left NaN): a Cholesky pivot
+ * at or below 1e-11 of its column's own centred diagonal entry counts as zero (a column the ones
+ * before it explain to rounding error, i.e. collinear features).  F <= 24 with P <= 4 is solved by
+ * one wave in registers and needs no workspace; wider systems (the reference's 432 x 216) are
+ * factorised in 64-column blocks over many workgroups in the workspace, which must be 16-byte
+ * aligned. */
 size_t wm_normal_solve_workspace_bytes(int F, int P);
 int wm_normal_solve_f64(const double *acc, int F, int P, int fit_intercept, double ridge,
                         double *beta, int *status,

@@ -165,3 +165,126 @@ def test_gram_x64_asymmetric_integers_are_exact():
     Y = ((r * 5) % 13) - 4.0
     a = ops.gram(_dev(X), _dev(Y)).cpu().numpy()
     assert np.array_equal(a, ocpu.gram(X, Y))
+
+
+# ---------------------------------------------------------------------------------------------
+# round 3: the VALU stream for narrow problems (gram_small.hip) and the LDS-staged blocked SYRK
+# for everything else (gram_syrk.hip) -- the reference's own shapes are F=2,P=1
+# (multipleRegression.py:35,273-286) and F=432,P=216 (singleRegression.py:21,33,74-85)
+
+SMALL_SHAPES = [(1, 1), (2, 1), (3, 1), (4, 1), (5, 1), (6, 1), (7, 1), (8, 1),
+                (4, 2), (6, 3), (8, 4), (10, 5), (5, 2), (5, 3)]
+
+
+def _int_problem(n, F, P):
+    """Small distinct integers, asymmetric in (row, column): products and sums are exact in
+    float32, so any Gram kernel must reproduce the float64 oracle bit for bit."""
+    r = np.arange(n, dtype=np.float32)[:, None]
+    f = np.arange(F, dtype=np.float32)[None, :]
+    p = np.arange(P, dtype=np.float32)[None, :]
+    X = ((r * 7 + f * f * 3 + f * 5) % 11) + (f % 7)
+    Y = ((r * 5 + p * 3) % 13) - 4.0 + (p % 5)
+    return np.ascontiguousarray(X, np.float32), np.ascontiguousarray(Y, np.float32)
+
+
+@pytest.mark.parametrize("F,P", SMALL_SHAPES, ids=[f"f{f}p{p}" for f, p in SMALL_SHAPES])
+def test_gram_small_every_instantiated_shape(F, P):
+    from weather_model_amd import ops, synth
+    from oracle import cpu as ocpu
+    # exact integers: layout slips (row/column order, lane-to-row map) permute entries
+    for n in (1, 67, 64 * 4 * 8 * 2 + 259):
+        X, Y = _int_problem(n, F, P)
+        a = ops.gram(_dev(X), _dev(Y)).cpu().numpy()
+        assert np.array_equal(a, ocpu.gram(X, Y)), (F, P, n)
+    # random rows, enough of them for several batches per wave and a float64 flush
+    n = 3_000_017
+    X, Y, _ = synth.regression_problem(n, F, P, seed=100 + F * 16 + P)
+    Xd, Yd = _dev(X), _dev(Y)
+    a = ops.gram(Xd, Yd)
+    ref = ocpu.gram(X, Y)
+    assert relinf(a.cpu().numpy(), ref) < 2e-6
+    assert torch.equal(ops.gram(Xd, Yd), a)                 # bitwise reproducible
+    beta = ops.normal_solve(a, F, P).cpu().numpy()
+    assert relinf(beta, ocpu.normal_solve(ref, F, P)) < COEF_TOL
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 127, 128, 129, 1023, 1024, 1025, 12 * 1024 + 1])
+def test_gram_small_ragged_rows_reference_shape(n):
+    """F=2, P=1 (multipleRegression's own fit): every row count around the batch boundaries."""
+    from weather_model_amd import ops, synth
+    from oracle import cpu as ocpu
+    X, Y, _ = synth.regression_problem(n, 2, 1, seed=77)
+    a = ops.gram(_dev(X), _dev(Y)).cpu().numpy()
+    assert a[2, 2] == n
+    assert relinf(a, ocpu.gram(X, Y)) < 2e-6
+
+
+def test_gram_small_unaligned_falls_back_and_agrees():
+    from weather_model_amd import ops, synth
+    X, Y, _ = synth.regression_problem(5001, 2, 1, seed=78)
+    Xd, Yd = _dev(X), _dev(Y)
+    fast = ops.gram(Xd, Yd)
+    buf = torch.empty(X.size + 1, device="cuda", dtype=torch.float32)
+    buf[1:] = Xd.reshape(-1)
+    slow = ops.gram(buf[1:].view(5001, 2), Yd)       # 4-byte aligned X: generic kernel
+    assert relinf(slow.cpu().numpy(), fast.cpu().numpy()) < 1e-6
+
+
+SYRK_SHAPES = [
+    # F, P: one tile (4-way k split); two tiles; three tiles in one superblock; two superblocks
+    # with a ragged last block; scalar fill (P % 4 != 0, F % 4 != 0); the reference's shape
+    (24, 8), (60, 4), (100, 12), (130, 2), (33, 7), (200, 56), (432, 216),
+]
+
+
+@pytest.mark.parametrize("F,P", SYRK_SHAPES, ids=[f"f{f}p{p}" for f, p in SYRK_SHAPES])
+def test_gram_syrk_shapes_exact_and_random(F, P):
+    from weather_model_amd import ops, synth
+    from oracle import cpu as ocpu
+    for n in (1, 63, 64, 65, 2 * 64 * 16 + 77):
+        X, Y = _int_problem(n, F, P)
+        a = ops.gram(_dev(X), _dev(Y)).cpu().numpy()
+        ref = ocpu.gram(X, Y)
+        assert np.array_equal(a, ref), (F, P, n, np.argwhere(a != ref)[:4])
+    n = 40_000 if F < 400 else 9_000
+    X, Y, _ = synth.regression_problem(n, F, P, seed=200 + F, dist="normal")
+    Xd, Yd = _dev(X), _dev(Y)
+    a = ops.gram(Xd, Yd)
+    ref = ocpu.gram(X, Y)
+    assert relinf(a.cpu().numpy(), ref) < 2e-6
+    assert torch.equal(ops.gram(Xd, Yd), a)
+    # running sum over two row chunks
+    h = n // 3
+    acc = ops.gram(Xd[:h], Yd[:h])
+    acc = ops.gram(Xd[h:], Yd[h:], acc)
+    assert relinf(acc.cpu().numpy(), ref) < 2e-6
+
+
+# the blocked multi-workgroup solve (solve_blocked.hip): every system beyond the one-wave kernel
+BLOCKED_SOLVES = [(25, 1), (40, 5), (64, 8), (65, 3), (100, 70), (128, 64), (200, 130), (432, 216)]
+
+
+@pytest.mark.parametrize("F,P", BLOCKED_SOLVES, ids=[f"f{f}p{p}" for f, p in BLOCKED_SOLVES])
+def test_blocked_solve_matches_float64_oracle(F, P):
+    from weather_model_amd import ops, synth
+    from oracle import cpu as ocpu
+    n = 6 * F + 50
+    X, Y, _ = synth.regression_problem(n, F, P, seed=300 + F, dist="normal")
+    ref = ocpu.gram(X, Y)
+    acc = _dev(ref)
+    for fi in (True, False):
+        for ridge in (0.0, 0.25):
+            b = ops.normal_solve(acc, F, P, fit_intercept=fi, ridge=ridge).cpu().numpy()
+            assert relinf(b, ocpu.normal_solve(ref, F, P, fi, ridge)) < 1e-9, (fi, ridge)
+    # and against numpy's least squares on the same rows (the coefficient tolerance of north_star)
+    A = np.concatenate([X.astype(np.float64), np.ones((n, 1))], 1)
+    ls = np.linalg.lstsq(A, Y.astype(np.float64), rcond=None)[0]
+    assert relinf(ops.normal_solve(acc, F, P).cpu().numpy(), ls) < 1e-8
+    # a collinear column in the LAST block: the pivot fails there, everything comes back NaN
+    Xc = X.copy()
+    Xc[:, F - 1] = Xc[:, 0]
+    accc = _dev(ocpu.gram(Xc, Y))
+    with pytest.raises(RuntimeError, match="positive definite"):
+        ops.normal_solve(accc, F, P)
+    assert np.isnan(ops.normal_solve(accc, F, P, check=False).cpu().numpy()).all()
+    assert np.isfinite(ops.normal_solve(accc, F, P, ridge=1e-3).cpu().numpy()).all()

@@ -35,8 +35,8 @@ def _stale(target, deps):
 
 def _compile(src, extra=()):
     obj = os.path.join(OBJ, src[:-4] + ".o")
-    deps = [os.path.join(CSRC, src), os.path.join(CSRC, "common.h"),
-            os.path.join(ROOT, "include", "wm.h")]
+    deps = [os.path.join(CSRC, src), os.path.join(ROOT, "include", "wm.h")] + \
+        [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
     if not _stale(obj, deps):
         return obj
     cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall",

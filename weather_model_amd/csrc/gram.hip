@@ -13,14 +13,17 @@
 //                       B = register r2 gives Gram entries (4a+r1, 4b+r2).  The 10 register pairs
 //                       r1 <= r2 cover the symmetric 16x16 block with every MFMA flop useful and no
 //                       LDS round trip.  X'y, column sums, y'y are VALU FMAs on the same registers.
-//   gram_tile_kernel    any F, P.  One 16x16 tile of Z'Z per block column, v_mfma_f32_16x16x4_f32,
-//                       operands loaded straight from global memory (row-major rows are the
-//                       operand layout), rows split over blockIdx.y.
-//   both keep float32 sums for at most 1024 rows per accumulator, then add them into float64
+//   gram_x64_kernel     F = 64, P = 1 (BASELINE config 5): the same idea on v_mfma_f32_16x16x4_f32.
+//   gram_small.hip      F + P <= 15 (the reference's multipleRegression shape F = 2, P = 1): VALU stream.
+//   gram_syrk.hip       every other shape (singleRegression's F = 432, P = 216): LDS-staged blocked
+//                       SYRK on MFMA.
+//   all keep float32 sums for at most 1024 rows per accumulator, then add them into float64
 //   registers; per-block float64 partials go to the workspace and a finalize kernel adds them to
 //   acc in a fixed order.
-//   normal_solve_kernel one workgroup, float64 Cholesky of the centred system.
-#include "common.h"
+//   normal_solve_*      float64 Cholesky of the centred system: one wave (F <= 24), one workgroup
+//                       in LDS, or blocked over many workgroups (solve_blocked.hip).
+#include "gram_internal.h"
+#include "solve_internal.h"
 
 namespace {
 
@@ -403,221 +406,7 @@ __global__ __launch_bounds__(64) void gram_x64_finalize_kernel(const double *__r
     if (threadIdx.x == 0) acc[e] += s;
 }
 
-// ---------------------------------------------------------------------------- generic tiles
-__device__ __forceinline__ float zval(const float *__restrict__ X, const float *__restrict__ Y,
-                                      long long row, int col, long long n, int F, int P, int D)
-{
-    if (row >= n || col >= D) return 0.0f;
-    if (col < F) return X[row * F + col];
-    if (col == F) return 1.0f;
-    return Y[row * P + (col - F - 1)];
-}
-
-constexpr int TILE_FLUSH_STEPS = 256;   // 256 steps x 4 rows = 1024 products per accumulator
-
-// grid = (tile pairs (ti <= tj), row slices).  partial: [slices][pairs][256] float64, element
-// index reg*64 + lane of the 16x16x4 accumulator (row = (lane>>4)*4 + reg, col = lane&15).
-__global__ __launch_bounds__(BLOCK) void gram_tile_kernel(const float *__restrict__ X,
-                                                          const float *__restrict__ Y, long long n,
-                                                          int F, int P, int DT,
-                                                          double *__restrict__ partial)
-{
-    __shared__ double red[WAVES][4][64];
-    const int D = F + 1 + P;
-    // decode the upper-triangular pair index
-    int pair = blockIdx.x, ti = 0;
-    while (pair >= DT - ti) { pair -= DT - ti; ++ti; }
-    const int tj = ti + pair;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const long long steps = (n + 3) >> 2;
-    const long long nchunks = (long long)gridDim.y * WAVES;
-    const long long chunk = (long long)blockIdx.y * WAVES + wv;
-    const long long s0 = steps * chunk / nchunks, s1 = steps * (chunk + 1) / nchunks;
-    const int k = lane >> 4;
-    const int ca = ti * 16 + (lane & 15), cb = tj * 16 + (lane & 15);
-    const bool diag = (ti == tj);
-
-    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-    double d[4] = {0.0, 0.0, 0.0, 0.0};
-    int since = 0;
-    long long s = s0;
-    for (; s + 4 <= s1; s += 4) {
-        float av[4], bv[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const long long row = (s + u) * 4 + k;
-            av[u] = zval(X, Y, row, ca, n, F, P, D);
-            bv[u] = diag ? av[u] : zval(X, Y, row, cb, n, F, P, D);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
-        since += 4;
-        if (since >= TILE_FLUSH_STEPS) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { d[r] += (double)acc[r]; acc[r] = 0.f; }
-            since = 0;
-        }
-    }
-    for (; s < s1; ++s) {
-        const long long row = s * 4 + k;
-        const float av = zval(X, Y, row, ca, n, F, P, D);
-        const float bv = diag ? av : zval(X, Y, row, cb, n, F, P, D);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        d[r] += (double)acc[r];
-        red[wv][r][lane] = d[r];
-    }
-    __syncthreads();
-    {
-        const int r = threadIdx.x >> 6, l = threadIdx.x & 63;
-        double sum = 0.0;
-#pragma unroll
-        for (int w = 0; w < WAVES; ++w) sum += red[w][r][l];
-        partial[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x] = sum;
-    }
-}
-
-// grid = pairs, 256 threads: thread = one accumulator element; sums the slices in order.
-__global__ __launch_bounds__(BLOCK) void gram_tile_finalize_kernel(
-    const double *__restrict__ partial, int slices, int npairs, int DT, int D,
-    double *__restrict__ acc)
-{
-    int pair = blockIdx.x, ti = 0;
-    while (pair >= DT - ti) { pair -= DT - ti; ++ti; }
-    const int tj = ti + pair;
-    const int reg = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int gi = ti * 16 + (lane >> 4) * 4 + reg;
-    const int gj = tj * 16 + (lane & 15);
-    if (gi >= D || gj >= D) return;
-    double s = 0.0;
-    for (int sl = 0; sl < slices; ++sl)
-        s += partial[((size_t)sl * npairs + blockIdx.x) * 256 + threadIdx.x];
-    acc[(size_t)gi * D + gj] += s;
-    if (ti != tj) acc[(size_t)gj * D + gi] += s;
-}
-
-// ---------------------------------------------------------------------------- solve
-// One workgroup.  A, L (F x F) and B, Z (F x P) live in LDS when they fit, else in the workspace.
-// Every elimination step is ONE barrier-separated phase: the scaled column goes to a separate
-// array (L, Z, beta) so the trailing update can read the unscaled one in the same phase, and the
-// pivot reciprocal is recomputed by every thread instead of being broadcast through memory
-// (a 17 x 17 system: 3 F phases instead of 7 F; 28 -> ~10 us).
-template <bool USE_LDS>
-__global__ __launch_bounds__(BLOCK) void normal_solve_kernel(const double *__restrict__ acc, int F,
-                                                             int P, int fit_intercept, double ridge,
-                                                             double *__restrict__ beta,
-                                                             int *__restrict__ status,
-                                                             double *__restrict__ ws)
-{
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int D = F + 1 + P;
-    double *A = USE_LDS ? smem : ws;
-    double *L = A + (size_t)F * F;
-    double *B = L + (size_t)F * F;
-    double *Z = B + (size_t)F * P;
-    double *S = Z + (size_t)F * P;      // column sums of X   [F]
-    double *T = S + F;                  // column sums of Y   [P]
-    double *R = T + P;                  // 1 / L[k][k]        [F]
-    const int tid = threadIdx.x;
-    const int NT = blockDim.x;   // 64 (one wave) for small systems, else 256
-    // every global read of this kernel is issued in two parallel sweeps (a dependent chain of
-    // L2-miss latencies was most of the 28 us the first version took for a 17 x 17 system)
-    for (int i = tid; i < F; i += NT) S[i] = acc[(size_t)i * D + F];
-    for (int p = tid; p < P; p += NT) T[p] = acc[(size_t)F * D + F + 1 + p];
-    const double n = acc[(size_t)F * D + F];
-    const double inv_n = (fit_intercept && n > 0.0) ? 1.0 / n : 0.0;
-    bool bad = fit_intercept && !(n > 0.0);          // uniform: every thread sees the same values
-#pragma unroll 4
-    for (int e = tid; e < F * F; e += NT) A[e] = acc[(size_t)(e / F) * D + e % F];
-#pragma unroll 4
-    for (int e = tid; e < F * P; e += NT) B[e] = acc[(size_t)(e / P) * D + F + 1 + e % P];
-    __syncthreads();
-    for (int e = tid; e < F * F; e += NT) {
-        const int i = e / F, j = e % F;
-        double v = A[e] - S[i] * S[j] * inv_n;
-        if (i == j) v += ridge;
-        A[e] = v;
-    }
-    for (int e = tid; e < F * P; e += NT) B[e] -= S[e / P] * T[e % P] * inv_n;
-    __syncthreads();
-    // small systems (one wave): each lane's lower-triangle elements are fixed for the whole
-    // factorisation, so the (i, j) decode -- two integer divisions per element and step in the
-    // generic loop below, most of its instructions -- is done once
-    constexpr int SMALL_MAX = 24, SMALL_ELEMS = SMALL_MAX * SMALL_MAX / 64;
-    const bool small = USE_LDS && NT == 64 && F <= SMALL_MAX;
-    int ei[SMALL_ELEMS], ej[SMALL_ELEMS];
-    if (small) {
-#pragma unroll
-        for (int r = 0; r < SMALL_ELEMS; ++r) {
-            const int e = tid + 64 * r;
-            ei[r] = e / F;
-            ej[r] = e % F;
-            if (e >= F * F || ej[r] > ei[r]) ei[r] = -1;      // not a lower-triangle element
-        }
-    }
-    // right-looking Cholesky: L[i][k] = A[i][k] / sqrt(d), A[i][j] -= A[i][k] A[j][k] / d
-    for (int k = 0; k < F && !bad; ++k) {
-        const double dk = A[(size_t)k * F + k];
-        if (!(dk > 0.0)) { bad = true; break; }
-        // one reciprocal square root per step and no division anywhere: a float64 divide or
-        // square root is a long dependent chain, and this kernel is nothing but such chains
-        const double rs = rsqrt(dk), inv = rs * rs;
-        if (tid == 0) R[k] = rs;
-        for (int i = k + tid; i < F; i += NT) L[(size_t)i * F + k] = A[(size_t)i * F + k] * rs;
-        if (small) {
-#pragma unroll
-            for (int r = 0; r < SMALL_ELEMS; ++r)
-                if (ej[r] > k && ei[r] >= 0)              // j > k (and i >= j > k)
-                    A[ei[r] * F + ej[r]] -= A[ei[r] * F + k] * A[ej[r] * F + k] * inv;
-        } else {
-            const int m = F - k - 1;
-            for (int e = tid; e < m * m; e += NT) {
-                const int i = k + 1 + e / m, j = k + 1 + e % m;
-                if (j <= i)
-                    A[(size_t)i * F + j] -= A[(size_t)i * F + k] * A[(size_t)j * F + k] * inv;
-            }
-        }
-        __syncthreads();
-    }
-    if (!bad) {
-        // forward substitution L z = B (column oriented): Z[k] = B[k] / L[k][k]
-        for (int k = 0; k < F; ++k) {
-            const double rk = R[k];
-            for (int p = tid; p < P; p += NT) Z[(size_t)k * P + p] = B[(size_t)k * P + p] * rk;
-            const int m = F - k - 1;
-            for (int e = tid; e < m * P; e += NT) {
-                const int i = k + 1 + e / P, p = e % P;
-                B[(size_t)i * P + p] -= L[(size_t)i * F + k] * (B[(size_t)k * P + p] * rk);
-            }
-            __syncthreads();
-        }
-        // back substitution L' beta = z: B[k] = Z[k] / L[k][k] is the answer row
-        for (int k = F - 1; k >= 0; --k) {
-            const double rk = R[k];
-            for (int p = tid; p < P; p += NT) B[(size_t)k * P + p] = Z[(size_t)k * P + p] * rk;
-            for (int e = tid; e < k * P; e += NT) {
-                const int i = e / P, p = e % P;
-                Z[(size_t)i * P + p] -= L[(size_t)k * F + i] * (Z[(size_t)k * P + p] * rk);
-            }
-            __syncthreads();
-        }
-    }
-    const double qnan = __longlong_as_double(0x7ff8000000000000LL);
-    for (int e = tid; e < F * P; e += NT) beta[e] = bad ? qnan : B[e];
-    for (int p = tid; p < P; p += NT) {
-        double icpt = 0.0;
-        if (fit_intercept && !bad) {
-            icpt = T[p] * inv_n;
-            for (int i = 0; i < F; ++i) icpt -= S[i] * inv_n * B[(size_t)i * P + p];
-        }
-        beta[(size_t)F * P + p] = bad ? qnan : icpt;
-    }
-    if (tid == 0 && status) *status = bad ? 1 : 0;
-}
-
+// ---------------------------------------------------------------------------- predict
 __global__ __launch_bounds__(BLOCK) void linear_predict_kernel(const float *__restrict__ X,
                                                               const double *__restrict__ beta,
                                                               float *__restrict__ Yhat,
@@ -661,29 +450,13 @@ int f16_grid()
     return wm_num_cus() * 2;
 }
 
-void tile_plan(long long n, int F, int P, int *DT, int *pairs, int *slices)
-{
-    const int D = F + 1 + P;
-    *DT = (D + 15) / 16;
-    *pairs = *DT * (*DT + 1) / 2;
-    long long s = ((long long)wm_num_cus() * 8 + *pairs - 1) / *pairs;
-    const long long max_s = (n + 4095) / 4096;
-    if (s > max_s) s = max_s;
-    if (s < 1) s = 1;
-    if (s > 65535) s = 65535;
-    *slices = (int)s;
-}
-
-constexpr size_t SOLVE_LDS_LIMIT = 128 * 1024;   // one workgroup on the CU: most of its 160 KB
-
 }  // namespace
 
 extern "C" size_t wm_gram_workspace_bytes(int64_t n, int F, int P)
 {
     if (n <= 0 || F <= 0 || P <= 0 || wm_num_cus() <= 0) return 0;
-    int DT, pairs, slices;
-    tile_plan(n, F, P, &DT, &pairs, &slices);
-    size_t b = (size_t)slices * pairs * 256 * sizeof(double);
+    // the alignment of X and Y is not known here: the generic kernel must always fit
+    size_t b = wm_gram_syrk_workspace_bytes(n, F, P);
     if (F == 16 && P == 1) {
         const size_t b16 = (size_t)f16_grid() * F16_PART * sizeof(double);
         if (b16 > b) b = b16;
@@ -692,6 +465,8 @@ extern "C" size_t wm_gram_workspace_bytes(int64_t n, int F, int P)
         const size_t b64 = (size_t)x64_grid(n) * WAVES * X64_PART * sizeof(double);
         if (b64 > b) b = b64;
     }
+    const size_t bs = wm_gram_small_workspace_bytes(F, P);
+    if (bs > b) b = bs;
     return wm_align_up(b, 256);
 }
 
@@ -728,15 +503,9 @@ extern "C" int wm_gram_f32(const float *X, const float *Y, int64_t n, int F, int
         WM_LAUNCH_CHECK("gram_x64_finalize_kernel");
         return WM_OK;
     }
-    int DT, pairs, slices;
-    tile_plan(n, F, P, &DT, &pairs, &slices);
-    hipLaunchKernelGGL(gram_tile_kernel, dim3(pairs, slices), dim3(BLOCK), 0, st, X, Y,
-                       (long long)n, F, P, DT, partial);
-    WM_LAUNCH_CHECK("gram_tile_kernel");
-    hipLaunchKernelGGL(gram_tile_finalize_kernel, dim3(pairs), dim3(BLOCK), 0, st, partial, slices,
-                       pairs, DT, F + 1 + P, acc);
-    WM_LAUNCH_CHECK("gram_tile_finalize_kernel");
-    return WM_OK;
+    if (wm_gram_small_supported(X, Y, F, P))
+        return wm_gram_small_launch(X, Y, (long long)n, F, P, acc, partial, st);
+    return wm_gram_syrk_launch(X, Y, (long long)n, F, P, acc, workspace, st);
 }
 
 namespace {
@@ -769,7 +538,7 @@ __global__ __launch_bounds__(64) void normal_solve_wave_kernel(const double *__r
     const double inv_n = (fit_intercept && n > 0.0) ? 1.0 / n : 0.0;
     bool bad = fit_intercept && !(n > 0.0);
     const double si = acc[(size_t)i * D + F];
-    double a[WS_F], b[WS_P], T[WS_P];
+    double a[WS_F], b[WS_P], T[WS_P], d0 = 0.0;
 #pragma unroll
     for (int p = 0; p < WS_P; ++p) {
         T[p] = p < P ? acc[(size_t)F * D + F + 1 + p] : 0.0;
@@ -783,6 +552,7 @@ __global__ __launch_bounds__(64) void normal_solve_wave_kernel(const double *__r
             if (j == lane) v += ridge;
         }
         a[j] = v;
+        if (j == lane) d0 = v;                            // the column's own centred diagonal
     }
     double r[WS_F];                                       // 1 / L[k][k], wave-uniform
 #pragma unroll
@@ -790,7 +560,7 @@ __global__ __launch_bounds__(64) void normal_solve_wave_kernel(const double *__r
         r[k] = 0.0;
         if (k < F && !bad) {
             const double dk = readlane_f64(a[k], k);
-            if (!(dk > 0.0)) {
+            if (!(dk > WM_PIVOT_RTOL * readlane_f64(d0, k))) {    // collinear: solve_internal.h
                 bad = true;
             } else {
                 const double rs = rsqrt(dk), inv = rs * rs;
@@ -856,8 +626,8 @@ __global__ __launch_bounds__(64) void normal_solve_wave_kernel(const double *__r
 extern "C" size_t wm_normal_solve_workspace_bytes(int F, int P)
 {
     if (F <= 0 || P <= 0) return 0;
-    const size_t b = (2 * ((size_t)F * F + (size_t)F * P) + 2 * (size_t)F + P) * sizeof(double);
-    return b <= SOLVE_LDS_LIMIT ? 0 : wm_align_up(b, 256);
+    if (F <= WS_F && P <= WS_P) return 0;          // one wave, matrix in registers
+    return wm_solve_blocked_workspace_bytes(F, P);
 }
 
 extern "C" int wm_normal_solve_f64(const double *acc, int F, int P, int fit_intercept, double ridge,
@@ -868,37 +638,19 @@ extern "C" int wm_normal_solve_f64(const double *acc, int F, int P, int fit_inte
     WM_REQUIRE(F > 0 && P > 0, WM_ERR_INVALID, "wm_normal_solve_f64: bad sizes F=%d P=%d", F, P);
     WM_REQUIRE(ridge >= 0.0, WM_ERR_INVALID, "wm_normal_solve_f64: negative ridge");
     hipStream_t st = (hipStream_t)stream;
-    const size_t bytes = (2 * ((size_t)F * F + (size_t)F * P) + 2 * (size_t)F + P) * sizeof(double);
     if (F <= WS_F && P <= WS_P) {
         hipLaunchKernelGGL(normal_solve_wave_kernel, dim3(1), dim3(64), 0, st, acc, F, P,
                            fit_intercept, ridge, beta, status);
         WM_LAUNCH_CHECK("normal_solve_wave_kernel");
         return WM_OK;
     }
-    if (bytes <= SOLVE_LDS_LIMIT) {
-        // per device: the attribute belongs to the function's image on the current device
-        static bool attr_set_dev[64] = {};
-        int dev = 0;
-        WM_HIP(hipGetDevice(&dev));
-        bool &attr_set = attr_set_dev[dev & 63];
-        if (!attr_set) {
-            WM_HIP(hipFuncSetAttribute((const void *)normal_solve_kernel<true>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)SOLVE_LDS_LIMIT));
-            attr_set = true;
-        }
-        hipLaunchKernelGGL(normal_solve_kernel<true>, dim3(1), dim3(F <= 24 ? 64 : BLOCK), bytes, st, acc, F, P,
-                           fit_intercept, ridge, beta, status, (double *)nullptr);
-    } else {
-        const size_t need = wm_normal_solve_workspace_bytes(F, P);
-        WM_REQUIRE(workspace && workspace_bytes >= need, WM_ERR_WORKSPACE,
-                   "wm_normal_solve_f64: workspace of %zu bytes needed, %zu given", need,
-                   workspace_bytes);
-        hipLaunchKernelGGL(normal_solve_kernel<false>, dim3(1), dim3(BLOCK), 0, st, acc, F, P,
-                           fit_intercept, ridge, beta, status, (double *)workspace);
-    }
-    WM_LAUNCH_CHECK("normal_solve_kernel");
-    return WM_OK;
+    const size_t need = wm_normal_solve_workspace_bytes(F, P);
+    WM_REQUIRE(workspace && workspace_bytes >= need, WM_ERR_WORKSPACE,
+               "wm_normal_solve_f64: workspace of %zu bytes needed, %zu given", need,
+               workspace_bytes);
+    WM_REQUIRE((((uintptr_t)workspace) & 15) == 0, WM_ERR_INVALID,
+               "wm_normal_solve_f64: workspace must be 16-byte aligned");
+    return wm_solve_blocked_launch(acc, F, P, fit_intercept, ridge, beta, status, workspace, st);
 }
 
 extern "C" int wm_linear_predict_f32(const float *X, const double *beta, float *Yhat, int64_t n,

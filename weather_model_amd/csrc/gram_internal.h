@@ -1,0 +1,21 @@
+// gram_internal.h -- the Gram kernels behind wm_gram_f32, one translation unit per family.
+//   gram.hip        F = 16 / F = 64 with P = 1 (BASELINE configs 2 and 5), the solve, predict
+//   gram_small.hip  F + P <= 15 on the VALU, HBM-bound streaming (the reference's own
+//                   multipleRegression shape F = 2, P = 1: multipleRegression.py:35,273-286)
+//   gram_syrk.hip   every other shape: LDS-staged blocked Z'Z on fp32 MFMA (the reference's
+//                   singleRegression shape F = 432, P = 216: singleRegression.py:21,33,74-85)
+#pragma once
+
+#include "common.h"
+
+// F + P <= 15 and one of the instantiated (F, P) pairs, X 16-byte aligned, Y aligned to its vector
+// width.  Workspace: per-workgroup float64 partials.
+bool wm_gram_small_supported(const float *X, const float *Y, int F, int P);
+size_t wm_gram_small_workspace_bytes(int F, int P);
+int wm_gram_small_launch(const float *X, const float *Y, long long n, int F, int P, double *acc,
+                         double *partial, hipStream_t st);
+
+// Any F, P >= 1.  Workspace: per-wave float64 64 x 64 slabs (and 64 constant bytes in front).
+size_t wm_gram_syrk_workspace_bytes(long long n, int F, int P);
+int wm_gram_syrk_launch(const float *X, const float *Y, long long n, int F, int P, double *acc,
+                        void *workspace, hipStream_t st);
