@@ -288,3 +288,22 @@ def test_blocked_solve_matches_float64_oracle(F, P):
         ops.normal_solve(accc, F, P)
     assert np.isnan(ops.normal_solve(accc, F, P, check=False).cpu().numpy()).all()
     assert np.isfinite(ops.normal_solve(accc, F, P, ridge=1e-3).cpu().numpy()).all()
+
+
+@pytest.mark.parametrize("F,P", [(24, 8), (100, 12), (200, 56), (432, 216)],
+                         ids=["one_pair", "diag_superblock", "six_pairs", "reference_shape"])
+def test_gram_syrk_balanced_schedule_large_n(F, P):
+    """Row counts large enough for the balanced persistent schedule (mode 1 of gram_syrk.hip):
+    exact on integers (any slip in the stage dealing or the slab map loses or doubles rows), and
+    within float32 product accuracy of the float64 oracle on random rows."""
+    from weather_model_amd import ops, synth
+    from oracle import cpu as ocpu
+    n = 140_000 + 37
+    X, Y = _int_problem(n, F, P)
+    Xd, Yd = _dev(X), _dev(Y)
+    a = ops.gram(Xd, Yd)
+    ref = ocpu.gram(X, Y)
+    assert np.array_equal(a.cpu().numpy(), ref)
+    assert torch.equal(ops.gram(Xd, Yd), a)
+    X, Y, _ = synth.regression_problem(n, F, P, seed=400 + F, dist="uniform")
+    assert relinf(ops.gram(_dev(X), _dev(Y)).cpu().numpy(), ocpu.gram(X, Y)) < 2e-6

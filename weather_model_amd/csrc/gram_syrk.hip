@@ -28,6 +28,7 @@
 // problem (D <= 64) gets.  Shapes whose rows are not 16-byte aligned (F or P not a multiple of 4)
 // and the last partial stage take a scalar fill.
 #include "gram_internal.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -67,9 +68,18 @@ __host__ __device__ inline SyTile sy_wave_tile(int I, int J, int NB64, int w)
             }
         }
     SyTile t;
-    t.ks = T == 1 ? 4 : (T == 2 ? 2 : 1);
-    const int ti = w / t.ks;
-    t.kpart = w % t.ks;
+    int ti;
+    if (T == 3) {
+        // a diagonal superblock: two diagonal tiles (10 MFMAs per k-step) and one full tile (16);
+        // the full one is split over two waves, so the waves carry 10 / 8 / 8 / 10
+        ti = w == 0 ? 0 : (w == 3 ? 2 : 1);
+        t.ks = ti == 1 ? 2 : 1;
+        t.kpart = ti == 1 ? w - 1 : 0;
+    } else {
+        t.ks = T == 1 ? 4 : (T == 2 ? 2 : 1);
+        ti = w / t.ks;
+        t.kpart = w % t.ks;
+    }
     t.active = ti < T;
     t.wi = t.active ? tb[ti][0] : 0;
     t.wj = t.active ? tb[ti][1] : 0;
@@ -136,43 +146,101 @@ __device__ __forceinline__ void sy_stage(const float *pa, const float *pb, int k
     }
 }
 
-// grid = npairs * S workgroups.  slabs: [S][npairs][WAVES][SY_SLAB] float64.
+// ---- who does what.  Two schedules:
+//  mode 0  grid = npairs x S: workgroup (pair, slice) walks one contiguous slice of the stages.
+//          Simple, but a full pair costs 16 MFMAs per k-step and wave, a diagonal one 10, an edge
+//          one 8: with one workgroup per (pair, slice) the CUs that drew two full pairs set the
+//          time and a quarter of the chip idles (F = 432, P = 216: 97 TFLOP/s; four times as many
+//          slices, dealt dynamically: 117, but 528 MB of slabs).
+//  mode 1  balanced and persistent: ONE workgroup of eight waves per CU -- two halves of four waves,
+//          each the workgroup of mode 0 on its own stage and LDS buffer, so what shares a SIMD is
+//          two waves of the same cost.  The chip is cut into G groups of XCDs (blockIdx % 8), every
+//          group takes a contiguous share of the stages, and inside a group pair p gets w[p]
+//          workgroups IN PROPORTION TO ITS COST, whose 2 w[p] halves deal the group's stages
+//          round-robin (half h: stages h, h + 2 w[p], ...).  All pairs then advance through the
+//          rows at the same rate, so the workgroups of a group stream one compact window (cache
+//          hits for all but the first reader) and finish together; one slab per wave.
+//          (Two independent four-wave workgroups per CU with the same dealing gained 4 %: the
+//          dispatcher co-locates workgroups of different cost, and a SIMD shared by a 16- and a
+//          10-MFMA wave runs both at the pace of 26.)
+constexpr int SY_MAXP = 64;     // pairs a mode-1 plan can hold
+constexpr int SY_G = 2;         // XCD groups (four XCDs each)
+
+struct SyPlan {
+    int NB64, NSB, npairs, mode;
+    int S;                      // mode 0: slices
+    int slots, used;            // mode 1: workgroup slots per group, slots in use
+    short w[SY_MAXP], off[SY_MAXP + 1];
+};
+
+struct SyWork {
+    int pair;
+    long long t_first, t_end, t_step;
+    size_t slab_wg;             // slab index of the workgroup (x WAVES + wave)
+    bool valid;
+};
+
+__device__ __forceinline__ SyWork sy_assign(const SyPlan &pl, int bid, int half, long long stages)
+{
+    SyWork k;
+    k.valid = true;
+    if (pl.mode == 0) {
+        int slice;
+        if (pl.S % 8 == 0) {     // workgroups of one slice share an XCD
+            const int xcd = bid & 7, local = bid >> 3;
+            k.pair = local % pl.npairs;
+            slice = (local / pl.npairs) * 8 + xcd;
+        } else {
+            k.pair = bid % pl.npairs;
+            slice = bid / pl.npairs;
+        }
+        k.t_first = stages * slice / pl.S;
+        k.t_end = stages * (slice + 1) / pl.S;
+        k.t_step = 1;
+        k.slab_wg = (size_t)slice * pl.npairs + k.pair;
+    } else {
+        constexpr int PER = 8 / SY_G;                    // XCDs per group
+        const int xcd = bid & 7, g = xcd / PER;
+        const int l = (bid >> 3) * PER + xcd % PER;      // slot inside the group
+        k.valid = l < pl.used;
+        int p = 0;
+        while (p + 1 < pl.npairs && pl.off[p + 1] <= l) ++p;
+        k.pair = p;
+        k.t_first = stages * g / SY_G + 2 * (l - pl.off[p]) + half;
+        k.t_end = stages * (g + 1) / SY_G;
+        k.t_step = 2 * pl.w[p];
+        k.slab_wg = (size_t)bid * 2 + half;
+    }
+    return k;
+}
+
+// slabs: [workgroup (x 2 halves)][WAVES][SY_SLAB] float64.
 // FAST: rows are 16-byte aligned and n is a multiple of SY_ROWS (LDS-direct fill); otherwise a
 // scalar fill that takes any shape and zero-fills the rows past n.
-template <bool FAST>
-__global__ __launch_bounds__(BLOCK, 2) void gram_syrk_kernel(const float *__restrict__ X,
-                                                             const float *__restrict__ Y,
-                                                             long long n, int F, int P, int NB64,
-                                                             int NSB, int npairs, int S,
-                                                             const float *__restrict__ consts,
-                                                             double *__restrict__ slabs)
+// HALVES: 1 = mode 0 (four waves), 2 = mode 1 (eight waves, two stages in flight).
+template <bool FAST, int HALVES>
+__global__ __launch_bounds__(BLOCK * HALVES, 2) void gram_syrk_kernel(
+    const float *__restrict__ X, const float *__restrict__ Y, long long n, int F, int P,
+    const SyPlan pl, const float *__restrict__ consts, double *__restrict__ slabs)
 {
-    __shared__ __attribute__((aligned(16))) float smem[2 * SY_PANEL];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    extern __shared__ __attribute__((aligned(16))) float smem_all[];
+    const int tid = threadIdx.x & (BLOCK - 1), lane = tid & 63, wv = tid >> 6;
+    const int half = threadIdx.x / BLOCK;                 // wave-uniform
+    float *smem = smem_all + half * 2 * SY_PANEL;
     const int M = F + P;
-    // workgroups of one row slice share an XCD (blockIdx % 8) when the slices divide over the eight
-    int pair, slice;
-    if (S % 8 == 0) {
-        const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
-        pair = local % npairs;
-        slice = (local / npairs) * 8 + xcd;
-    } else {
-        pair = blockIdx.x % npairs;
-        slice = blockIdx.x / npairs;
-    }
-    int I, J;
-    sy_pair_decode(pair, NSB, &I, &J);
-    const bool two_panels = I != J;
-    const SyTile tile = sy_wave_tile(I, J, NB64, wv);
-    const bool diag = tile.bi == tile.bj;
-
     const long long stages = (n + SY_ROWS - 1) / SY_ROWS;
-    const long long t0 = stages * slice / S, t1 = stages * (slice + 1) / S;
+    const SyWork wk = sy_assign(pl, blockIdx.x, half, stages);
+    if (!wk.valid) return;                                // a spare slot: uniform, before any barrier
+    int I, J;
+    sy_pair_decode(wk.pair, pl.NSB, &I, &J);
+    const bool two_panels = I != J;
+    const SyTile tile = sy_wave_tile(I, J, pl.NB64, wv);
+    const bool diag = tile.bi == tile.bj;
 
     // fill: lane (lr, lc) of a wave instruction takes 4 columns at lc of panel row 2k + lr
     const int lr = lane >> 5, lc = 4 * (lane & 31);
     const float *src[2];
-    long long sstride[2];
+    long long sstride[2], sskip[2];
     if (FAST) {
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
@@ -181,8 +249,9 @@ __global__ __launch_bounds__(BLOCK, 2) void gram_syrk_kernel(const float *__rest
             else if (v < M) { src[p] = Y + (v - F); sstride[p] = P; }
             else if (v == M) { src[p] = consts; sstride[p] = 0; }
             else { src[p] = consts + 4; sstride[p] = 0; }
-            src[p] += (t0 * SY_ROWS + 2 * wv + lr) * sstride[p];
-            sstride[p] *= 2 * WAVES;                       // rows between two of a wave's loads
+            src[p] += (wk.t_first * SY_ROWS + 2 * wv + lr) * sstride[p];
+            sskip[p] = (wk.t_step - 1) * SY_ROWS * sstride[p];    // the stages of the other workgroups
+            sstride[p] *= 2 * WAVES;                              // rows between two of a wave's loads
         }
     }
     // operands: lane (i, g) reads columns 4i..4i+3 of row 4s + g of its tile's 64-column half
@@ -198,8 +267,14 @@ __global__ __launch_bounds__(BLOCK, 2) void gram_syrk_kernel(const float *__rest
     for (int k = 0; k < 64; ++k) d[k] = 0.0;
     int since = 0;
 
-    for (long long t = t0; t < t1; ++t) {
-        __syncthreads();                                  // every wave is past its reads
+    // both halves run the same number of trips (the barriers are the workgroup's): half 0 never
+    // has fewer stages than half 1, and a half past its last stage idles through the barriers
+    const long long first0 = wk.t_first - half;
+    const long long trips = first0 < wk.t_end ? (wk.t_end - first0 + wk.t_step - 1) / wk.t_step : 0;
+    long long t_load = wk.t_first;                        // the stage the next fill brings in
+
+    auto fill = [&]() {
+        if (t_load >= wk.t_end) return;
         if (FAST) {
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
@@ -209,9 +284,10 @@ __global__ __launch_bounds__(BLOCK, 2) void gram_syrk_kernel(const float *__rest
                     WM_GLDS16(src[p], smem + p * SY_PANEL + 2 * (wv + WAVES * m) * SY_PC);
                     src[p] += sstride[p];
                 }
+                src[p] += sskip[p];
             }
         } else {
-            const long long row0 = t * SY_ROWS;
+            const long long row0 = t_load * SY_ROWS;
             for (int p = 0; p < (two_panels ? 2 : 1); ++p) {
                 const int vb = (p == 0 ? I : J) * SY_PC;
                 for (int e = tid; e < SY_PANEL; e += BLOCK)
@@ -219,8 +295,10 @@ __global__ __launch_bounds__(BLOCK, 2) void gram_syrk_kernel(const float *__rest
                         sy_zval(X, Y, row0 + e / SY_PC, vb + e % SY_PC, n, F, P);
             }
         }
-        __syncthreads();                                  // vmcnt(0) + barrier: the panels landed
-        if (tile.active) {
+        t_load += wk.t_step;
+    };
+    auto multiply = [&](bool live) {
+        if (tile.active && live) {
             if (diag) sy_stage<true>(pa, pa, tile.kpart, tile.ks, c);
             else sy_stage<false>(pa, pb, tile.kpart, tile.ks, c);
         }
@@ -234,9 +312,32 @@ __global__ __launch_bounds__(BLOCK, 2) void gram_syrk_kernel(const float *__rest
                 }
             since = 0;
         }
+    };
+    if (HALVES == 1) {
+        for (long long it = 0; it < trips; ++it) {
+            __syncthreads();                              // every wave is past its reads
+            fill();
+            __syncthreads();                              // vmcnt(0) + barrier: the panels landed
+            multiply(true);
+        }
+    } else {
+        // The halves alternate: while one fills its buffer the other multiplies, so the LDS-direct
+        // loads of a CU always run beside MFMAs.  (In step -- both filling, then both multiplying
+        // -- the pass took fill time PLUS multiply time: 5.6 ms where the MFMAs alone take 3.85.)
+        long long t_mul = wk.t_first;                     // the stage the next multiply works on
+        if (half == 1) fill();
+        __syncthreads();
+        for (long long it = 0; it < trips; ++it) {
+            if (half == 0) fill();
+            else { multiply(t_mul < wk.t_end); t_mul += wk.t_step; }
+            __syncthreads();
+            if (half == 0) { multiply(t_mul < wk.t_end); t_mul += wk.t_step; }
+            else fill();
+            __syncthreads();
+        }
     }
     if (!tile.active) return;
-    double *dst = slabs + (((size_t)slice * npairs + pair) * WAVES + wv) * SY_SLAB;
+    double *dst = slabs + (wk.slab_wg * WAVES + wv) * SY_SLAB;
 #pragma unroll
     for (int k = 0; k < 16; ++k)
 #pragma unroll
@@ -249,15 +350,15 @@ __global__ void gram_syrk_consts_kernel(float *consts)
 }
 
 // grid = (64 x 64 tiles (bi <= bj), 16), one slab element per thread.  Sums the slabs of every
-// slice and of every wave that shared the tile, in a fixed order, and adds to acc (both triangles).
-// (One workgroup per tile with 16 elements per thread took 1.5 ms at F = 432: 66 workgroups, each
-// thread a chain of 16 x S dependent-latency loads.)
+// workgroup that worked on the tile's pair and of every wave that shared the tile, in a fixed
+// order, and adds to acc (both triangles).  (One workgroup per tile with 16 elements per thread
+// took 1.5 ms at F = 432: 66 workgroups, each thread a chain of 16 x S dependent-latency loads.)
 __global__ __launch_bounds__(BLOCK) void gram_syrk_finalize_kernel(const double *__restrict__ slabs,
-                                                                   int F, int P, int NB64, int NSB,
-                                                                   int npairs, int S,
+                                                                   int F, int P, const SyPlan pl,
                                                                    double *__restrict__ acc)
 {
     const int M = F + P, D = M + 1;
+    const int NB64 = pl.NB64, NSB = pl.NSB;
     int bi = 0, rest = blockIdx.x;
     while (rest >= NB64 - bi) {
         rest -= NB64 - bi;
@@ -274,46 +375,140 @@ __global__ __launch_bounds__(BLOCK) void gram_syrk_finalize_kernel(const double 
         if (t.active && t.bi == bi && t.bj == bj) wlist[nw++] = w;
     }
     const bool diag = bi == bj;
-    {
-        const int e = blockIdx.y * BLOCK + threadIdx.x;
-        const int lane = e & 63, r = (e >> 6) & 3, q2 = (e >> 8) & 3, q1 = e >> 10;
-        if (diag && q1 > q2) return;
-        const int va = bi * 64 + 4 * ((lane >> 4) * 4 + r) + q1;
-        const int vb = bj * 64 + 4 * (lane & 15) + q2;
-        if (va > M || vb > M) return;
-        double s = 0.0;
+    const int e = blockIdx.y * BLOCK + threadIdx.x;
+    const int lane = e & 63, r = (e >> 6) & 3, q2 = (e >> 8) & 3, q1 = e >> 10;
+    if (diag && q1 > q2) return;
+    const int va = bi * 64 + 4 * ((lane >> 4) * 4 + r) + q1;
+    const int vb = bj * 64 + 4 * (lane & 15) + q2;
+    if (va > M || vb > M) return;
+    double s = 0.0;
+    if (pl.mode == 0) {
         for (int k = 0; k < nw; ++k) {
             const double *src = slabs + ((size_t)pair * WAVES + wlist[k]) * SY_SLAB + e;
-            const size_t step = (size_t)npairs * WAVES * SY_SLAB;
+            const size_t step = (size_t)pl.npairs * WAVES * SY_SLAB;
 #pragma unroll 8
-            for (int sl = 0; sl < S; ++sl) s += src[sl * step];
+            for (int sl = 0; sl < pl.S; ++sl) s += src[sl * step];
         }
-        // virtual order [X | Y | 1] -> acc order [X | 1 | Y]
-        const int a = va < F ? va : (va < M ? va + 1 : F);
-        const int b = vb < F ? vb : (vb < M ? vb + 1 : F);
-        acc[(size_t)a * D + b] += s;
-        if (a != b && !(diag && q1 == q2)) acc[(size_t)b * D + a] += s;
+    } else {
+        constexpr int PER = 8 / SY_G;
+        const int wp = pl.w[pair], o = pl.off[pair];
+        for (int k = 0; k < nw; ++k)
+            for (int g = 0; g < SY_G; ++g) {
+#pragma unroll 4
+                for (int j = 0; j < 2 * wp; ++j) {
+                    const int l = o + (j >> 1);
+                    const size_t bid = (size_t)(l / PER) * 8 + g * PER + l % PER;
+                    s += slabs[((bid * 2 + (j & 1)) * WAVES + wlist[k]) * SY_SLAB + e];
+                }
+            }
     }
+    // virtual order [X | Y | 1] -> acc order [X | 1 | Y]
+    const int a = va < F ? va : (va < M ? va + 1 : F);
+    const int b = vb < F ? vb : (vb < M ? vb + 1 : F);
+    acc[(size_t)a * D + b] += s;
+    if (a != b && !(diag && q1 == q2)) acc[(size_t)b * D + a] += s;
 }
 
-struct SyPlan {
-    int NB64, NSB, npairs, S;
-};
-
-SyPlan sy_plan(long long n, int F, int P)
+// MFMAs per k-step on the busiest wave of the workgroup of pair (I, J): what its stages cost
+float sy_pair_cost(int I, int J, int NB64)
 {
-    SyPlan p;
+    int T = 0;
+    for (int wi = 0; wi < 2; ++wi)
+        for (int wj = 0; wj < 2; ++wj)
+            if (2 * I + wi <= 2 * J + wj && 2 * J + wj < NB64) ++T;
+    return T == 4 ? 16.f : (T == 3 ? 10.f : (T == 2 ? 8.f : 2.5f));
+}
+
+SyPlan sy_plan(long long n, int F, int P, bool fast)
+{
+    SyPlan p = {};
     const int D = F + P + 1;
     p.NB64 = (D + 63) / 64;
     p.NSB = (p.NB64 + 1) / 2;
     p.npairs = p.NSB * (p.NSB + 1) / 2;
     const long long stages = (n + SY_ROWS - 1) / SY_ROWS;
-    long long S = ((long long)wm_num_cus() * 2) / p.npairs;      // two workgroups per CU
+    const int wgs = wm_num_cus() * 2;                            // two four-wave workgroups per CU
+    int slots = wm_num_cus() / SY_G;                             // mode 1: one eight-wave workgroup
+    slots -= slots % (8 / SY_G);
+    bool balanced = fast && wm_num_cus() % 8 == 0 && p.npairs <= SY_MAXP && p.npairs <= slots &&
+                    stages >= 4LL * wgs;
+#ifdef WM_PROBE_ENV
+    if (const char *e = getenv("WM_SY_MODE")) balanced = balanced && atoi(e) != 0;
+#endif
+    if (balanced) {
+        p.mode = 1;
+        p.slots = slots;
+        float cost[SY_MAXP], total = 0.f;
+        for (int q = 0; q < p.npairs; ++q) {
+            int I, J;
+            sy_pair_decode(q, p.NSB, &I, &J);
+            cost[q] = sy_pair_cost(I, J, p.NB64);
+            total += cost[q];
+        }
+        // proportional shares, at least one workgroup each, the rest by largest remainder
+        float frac[SY_MAXP];
+        int given = 0;
+        for (int q = 0; q < p.npairs; ++q) {
+            const float share = slots * cost[q] / total;
+            int w = (int)share;
+            if (w < 1) w = 1;
+            p.w[q] = (short)w;
+            frac[q] = share - w;
+            given += w;
+        }
+        while (given > slots) {               // the "at least one" floor overshot: trim the largest
+            int big = 0;
+            for (int q = 1; q < p.npairs; ++q)
+                if (p.w[q] > p.w[big]) big = q;
+            --p.w[big];
+            --given;
+        }
+        while (given < slots) {
+            int best = 0;
+            for (int q = 1; q < p.npairs; ++q)
+                if (frac[q] > frac[best]) best = q;
+            if (frac[best] <= 0.f) break;
+            ++p.w[best];
+            frac[best] = -1.f;
+            ++given;
+        }
+        p.off[0] = 0;
+        for (int q = 0; q < p.npairs; ++q) p.off[q + 1] = (short)(p.off[q] + p.w[q]);
+        p.used = given;
+        return p;
+    }
+    p.mode = 0;
+    long long S = (long long)wgs / p.npairs;
     if (S >= 8) S -= S % 8;                                      // whole XCD rounds
+#ifdef WM_PROBE_ENV
+    if (const char *e = getenv("WM_SY_SLICES")) S = atoll(e);
+#endif
     if (S > stages) S = stages;
     if (S < 1) S = 1;
     p.S = (int)S;
     return p;
+}
+
+int sy_lds_once(const void *fn, size_t bytes, int slot)
+{
+    static bool done[64][3] = {};
+    int dev = 0;
+    WM_HIP(hipGetDevice(&dev));
+    bool &d = done[dev & 63][slot];
+    if (!d) {
+        WM_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        d = true;
+    }
+    return WM_OK;
+}
+
+size_t sy_plan_wgs(const SyPlan &p)      // workgroups launched
+{
+    return p.mode == 0 ? (size_t)p.npairs * p.S : (size_t)p.slots * SY_G;
+}
+size_t sy_plan_slabs(const SyPlan &p)    // four-wave slab groups written
+{
+    return p.mode == 0 ? (size_t)p.npairs * p.S : (size_t)p.slots * SY_G * 2;
 }
 
 }  // namespace
@@ -321,8 +516,9 @@ SyPlan sy_plan(long long n, int F, int P)
 size_t wm_gram_syrk_workspace_bytes(long long n, int F, int P)
 {
     if (n <= 0 || F <= 0 || P <= 0 || wm_num_cus() <= 0) return 0;
-    const SyPlan p = sy_plan(n, F, P);
-    return SY_CONST_BYTES + (size_t)p.S * p.npairs * WAVES * SY_SLAB * sizeof(double);
+    // the alignment of X and Y is not known here: room for either schedule
+    const size_t a = sy_plan_slabs(sy_plan(n, F, P, true)), b = sy_plan_slabs(sy_plan(n, F, P, false));
+    return SY_CONST_BYTES + (a > b ? a : b) * WAVES * SY_SLAB * sizeof(double);
 }
 
 int wm_gram_syrk_launch(const float *X, const float *Y, long long n, int F, int P, double *acc,
@@ -340,22 +536,33 @@ int wm_gram_syrk_launch(const float *X, const float *Y, long long n, int F, int 
         if (rows == 0) continue;
         const float *Xp = pass == 0 ? X : X + n_fast * F;
         const float *Yp = pass == 0 ? Y : Y + n_fast * P;
-        const SyPlan p = sy_plan(rows, F, P);
+        const SyPlan p = sy_plan(rows, F, P, pass == 0);
+        const int grid = (int)sy_plan_wgs(p);
+        const size_t lds = 2 * SY_PANEL * sizeof(float);
         if (pass == 0) {
             hipLaunchKernelGGL(gram_syrk_consts_kernel, dim3(1), dim3(64), 0, st, consts);
             WM_LAUNCH_CHECK("gram_syrk_consts_kernel");
-            hipLaunchKernelGGL(gram_syrk_kernel<true>, dim3(p.npairs * p.S), dim3(BLOCK), 0, st, Xp,
-                               Yp, rows, F, P, p.NB64, p.NSB, p.npairs, p.S,
-                               (const float *)consts, slabs);
+            if (p.mode == 1) {
+                int rc = sy_lds_once((const void *)gram_syrk_kernel<true, 2>, 2 * lds, 0);
+                if (rc != WM_OK) return rc;
+                hipLaunchKernelGGL((gram_syrk_kernel<true, 2>), dim3(grid), dim3(2 * BLOCK), 2 * lds,
+                                   st, Xp, Yp, rows, F, P, p, (const float *)consts, slabs);
+            } else {
+                int rc = sy_lds_once((const void *)gram_syrk_kernel<true, 1>, lds, 1);
+                if (rc != WM_OK) return rc;
+                hipLaunchKernelGGL((gram_syrk_kernel<true, 1>), dim3(grid), dim3(BLOCK), lds, st, Xp,
+                                   Yp, rows, F, P, p, (const float *)consts, slabs);
+            }
         } else {
-            hipLaunchKernelGGL(gram_syrk_kernel<false>, dim3(p.npairs * p.S), dim3(BLOCK), 0, st, Xp,
-                               Yp, rows, F, P, p.NB64, p.NSB, p.npairs, p.S,
-                               (const float *)consts, slabs);
+            int rc = sy_lds_once((const void *)gram_syrk_kernel<false, 1>, lds, 2);
+            if (rc != WM_OK) return rc;
+            hipLaunchKernelGGL((gram_syrk_kernel<false, 1>), dim3(grid), dim3(BLOCK), lds, st, Xp, Yp,
+                               rows, F, P, p, (const float *)consts, slabs);
         }
         WM_LAUNCH_CHECK("gram_syrk_kernel");
         const int ntiles = p.NB64 * (p.NB64 + 1) / 2;
         hipLaunchKernelGGL(gram_syrk_finalize_kernel, dim3(ntiles, SY_SLAB / BLOCK), dim3(BLOCK), 0, st,
-                           (const double *)slabs, F, P, p.NB64, p.NSB, p.npairs, p.S, acc);
+                           (const double *)slabs, F, P, p, acc);
         WM_LAUNCH_CHECK("gram_syrk_finalize_kernel");
     }
     return WM_OK;
