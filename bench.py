@@ -216,7 +216,8 @@ def gram_cpu_baselines(X, Y, F, P, beta_gpu):
     """CPU legs beside the Gram numbers (rank 0, N = 1): `cpu_baseline` = the library path the
     contract names (BASELINE.md 3 / SURVEY 8d: numpy float32 A.T @ A, A.T @ y with A = [X | 1], then
     a float64 lstsq of the normal equations), `cpu_baseline_port` = the repo's own C/OpenMP oracle."""
-    ns = 4_000_000 if F <= 16 else 1_000_000
+    ns = 4_000_000 if F <= 16 else (1_000_000 if F <= 64 else 100_000)
+    ns = min(ns, X.shape[0])
     Xs, Ys = X[:ns].cpu().numpy(), Y[:ns].cpu().numpy()
     out = {}
     A = np.concatenate([Xs, np.ones((ns, 1), np.float32)], axis=1)
@@ -233,7 +234,8 @@ def gram_cpu_baselines(X, Y, F, P, beta_gpu):
         "cpu": cpu_model_name(),
         "sample": f"{ns} of the same rows (F={F}): numpy float32 A.T@A, A.T@y (A=[X|1]) + float64 "
                   f"lstsq of the normal equations, BLAS threads, median of {reps}",
-        "coef_max_diff_vs_gpu": float(np.abs(sol[0][:F] - beta_gpu[:F]).max())}
+        "coef_max_diff_vs_gpu": float(np.abs(sol[0][:F] - beta_gpu[:F]).max()),
+        "coef_diff_note": "the CPU fit sees only the sample, the GPU fit all rows"}
     from oracle import cpu as ocpu
     bsol = [None]
 
@@ -249,28 +251,50 @@ def gram_cpu_baselines(X, Y, F, P, beta_gpu):
     return out
 
 
-def run_gram(F, n_rows, steps, warmup, rank, world, cpu_base):
+def gram_kernel_name(F, P):
+    if (F, P) == (16, 1):
+        return "gram_f16_kernel"
+    if (F, P) == (64, 1):
+        return "gram_x64_kernel"
+    return "gram_small_kernel" if F + P <= 15 else "gram_syrk_kernel"
+
+
+def run_gram(F, n_rows, steps, warmup, rank, world, cpu_base, P=1, dist="uniform"):
+    """Least squares with F predictors and P targets on n_rows resident rows per GPU: one step =
+    zero the accumulator, Gram pass, (N > 1: all-reduce of the (F+1+P)^2 float64 Gram), solve.
+    The roofline is the Gram kernel's: HBM (4(F+P) B/row) while F/2 flop/B is below the fp32 MFMA
+    ridge of 19.7, MFMA (2F(F+P) flop/row) above it."""
     from weather_model_amd import ops, synth, dp
-    P = 1
     beta_true = synth.normal(1001, (F, P))
     # rows of this rank: global row index keeps the data independent of the GPU count
     row_off = rank * n_rows
-    # generate in slabs to bound the transient footprint
     X = torch.empty((n_rows, F), device="cuda", dtype=torch.float32)
     Y = torch.empty((n_rows, P), device="cuda", dtype=torch.float32)
-    slab = 25_000_000
     bt = torch.from_numpy(beta_true).cuda()
     from weather_model_amd import _lib
     L = _lib.lib()
     st = torch.cuda.current_stream().cuda_stream
-    for s0 in range(0, n_rows, slab):
-        m = min(slab, n_rows - s0)
-        _lib.check(L.wm_synth_regression_f32(X[s0:].data_ptr(), Y[s0:].data_ptr(), m, F, P, 1,
-                                             row_off + s0, bt.data_ptr(), 0.5, 0.01, 0, st))
+    if P == 1:
+        slab = 25_000_000          # generate in slabs to bound the transient footprint
+        for s0 in range(0, n_rows, slab):
+            m = min(slab, n_rows - s0)
+            _lib.check(L.wm_synth_regression_f32(X[s0:].data_ptr(), Y[s0:].data_ptr(), m, F, P, 1,
+                                                 row_off + s0, bt.data_ptr(), 0.5, 0.01,
+                                                 1 if dist == "normal" else 0, st))
+    else:
+        # many targets: the per-row generator would hash every feature once per target; the rows
+        # come from the same counter-based stream, the targets from one library product (set-up
+        # only, outside every timed region), noise uniform with standard deviation 0.01
+        _lib.check(L.wm_synth_uniform_f32(X.data_ptr(), n_rows * F, 1, row_off * F, 0.0, 1.0, st))
+        _lib.check(L.wm_synth_uniform_f32(Y.data_ptr(), n_rows * P, 2001, row_off * P,
+                                          -0.01 * 3 ** 0.5, 0.01 * 3 ** 0.5, st))
+        slab = 250_000
+        for s0 in range(0, n_rows, slab):
+            Y[s0:s0 + slab].add_(X[s0:s0 + slab] @ bt + 0.5)
     torch.cuda.synchronize()
     plan = ops.GramPlan(n_rows, F, P, "cuda")
 
-    evs = []
+    evs, sevs = [], []
 
     def step(i, timed):
         plan.acc.zero_()
@@ -278,15 +302,19 @@ def run_gram(F, n_rows, steps, warmup, rank, world, cpu_base):
         # costs a few microseconds on the stream)
         timed = timed and (steps < 4 or i % 2 == 0)
         if timed:
-            e = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
             e[0].record()
         plan.accumulate(X, Y)
         if timed:
             e[1].record()
-            evs.append(e)
         if world > 1:
-            dp.reduce_gram_(plan.acc)            # the one exchange step: (F+2)x(F+2) float64
+            dp.reduce_gram_(plan.acc)            # the one exchange step: (F+1+P)^2 float64
         plan.solve()
+        if timed:
+            if world == 1:
+                e[2].record()
+                sevs.append((e[1], e[2]))
+            evs.append((e[0], e[1]))
 
     total = timed_steps(step, steps, warmup, world)
     kern_ms = [a.elapsed_time(c) for a, c in evs]
@@ -302,21 +330,37 @@ def run_gram(F, n_rows, steps, warmup, rank, world, cpu_base):
         "planted_coef_max_err": err,
         "kernel_ms_avg": kavg * 1e3,
     }
-    kname = "gram_f16_kernel" if F == 16 else ("gram_x64_kernel" if F == 64 else "gram_tile_kernel")
-    default_shape = F == 16 and n_rows == 100_000_000
-    ach = bytes_per_row * n_rows / kavg / 1e9
-    res["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                       "frac": ach / HBM_PEAK_GBS,
-                       "traffic": pmc_traffic([kname], default_shape),
-                       "traffic_source": pmc_source([kname], default_shape),
-                       "kernel": kname, "algorithmic_bytes_per_row": bytes_per_row,
-                       "algorithmic_flops_per_row": flops_per_row,
-                       "TFLOPs_algorithmic": flops_per_row * n_rows / kavg / 1e12}
+    if sevs:
+        res["solve_ms_avg"] = float(np.mean([a.elapsed_time(c) for a, c in sevs]))
+    kname = gram_kernel_name(F, P)
+    default_shape = (F, P, n_rows, dist) == (16, 1, 100_000_000, "uniform")
+    gbs = bytes_per_row * n_rows / kavg / 1e9
+    tf = flops_per_row * n_rows / kavg / 1e12
+    if flops_per_row / bytes_per_row < MFMA_F32_PEAK_TF * 1e3 / HBM_PEAK_GBS:
+        res["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": gbs / HBM_PEAK_GBS}
+    else:
+        res["roofline"] = {"bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TF,
+                           "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF,
+                           "hbm_GBs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS}
+    res["roofline"].update({"traffic": pmc_traffic([kname], default_shape),
+                            "traffic_source": pmc_source([kname], default_shape),
+                            "kernel": kname, "algorithmic_bytes_per_row": bytes_per_row,
+                            "algorithmic_flops_per_row": flops_per_row,
+                            "TFLOPs_algorithmic": tf})
     if cpu_base and rank == 0 and world == 1:
         res.update(gram_cpu_baselines(X, Y, F, P, beta))
     del X, Y
     torch.cuda.empty_cache()
     return res
+
+
+def gram_config(F, P, rows, world, dist, what):
+    return {"workload": f"{what}: F={F}, P={P}, {rows} rows per GPU, "
+                        f"X~{'N(0,1)' if dist == 'normal' else 'U(0,1)'}, Gram (fp32, fp64 combine) "
+                        f"+ normal-equation solve",
+            "rows_per_gpu": rows, "features": F, "targets": P,
+            "parallelism": f"dp{world} (row shards, one {F + 1 + P}x{F + 1 + P} f64 all-reduce)"}
 
 
 def run_gram64(steps, warmup, rank, world, cpu_base, rows_per_gpu, chunk_rows=50_000_000):
@@ -1036,7 +1080,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="all", choices=["all", "gram16", "conv3x3", "gram64", "model32", "fields", "conv32", "conv32x3",
-                             "conv3d_model", "plumbing"])
+                             "conv3d_model", "plumbing", "gram_ref_multi", "gram_ref_single",
+                             "gram16_normal"])
     ap.add_argument("--rows", type=int, default=100_000_000, help="rows per GPU (gram16)")
     ap.add_argument("--rows64", type=int, default=1_250_000_000,
                     help="rows per GPU of the F=64 workload (config 5: 1e10 rows / 8 GPUs)")
@@ -1094,6 +1139,34 @@ def main():
         for k in ("cpu_baseline", "cpu_baseline_port"):
             if k in r:
                 out[k] = r[k]
+    # the reference's OWN regression shapes, and config 2's second distribution
+    for name, (F_, P_, rows_, dist_, what) in {
+            "gram_ref_multi": (2, 1, 400_000_000, "uniform",
+                               "multipleRegression's own fit (CUBE_SIZE 1, one variable: "
+                               "multipleRegression.py:35,273-286)"),
+            "gram_ref_single": (432, 216, 1_000_000, "uniform",
+                                "singleRegression's own fit (6^3 cubes of T: "
+                                "singleRegression.py:21,33,74-85)"),
+            "gram16_normal": (16, 1, args.rows, "normal",
+                              "multipleRegression least squares on standardised features "
+                              "(multipleRegression.py:195-197)")}.items():
+        if args.workload not in ("all", name):
+            continue
+        kk = args.steps if args.workload == name else min(args.steps, 10)
+        ww = args.warmup if args.workload == name else min(args.warmup, 2)
+        r = run_gram(F_, rows_, kk, ww, rank, world, cpu_base, P=P_, dist=dist_)
+        r["steps"], r["warmup"] = kk, ww
+        r["config"] = gram_config(F_, P_, rows_, world, dist_, what)
+        if args.workload == name:
+            out.update({"metric": f"regression rows/s ({what})", "value": r["value"],
+                        "ms_per_step": r["ms_per_step"], "roofline": r["roofline"],
+                        "config": r["config"], "kernel_ms_avg": r["kernel_ms_avg"],
+                        "planted_coef_max_err": r["planted_coef_max_err"]})
+            for k in ("cpu_baseline", "cpu_baseline_port", "solve_ms_avg"):
+                if k in r:
+                    out[k] = r[k]
+        else:
+            out.setdefault("also", {})[name] = r
     if args.workload in ("all", "gram64"):
         # config 5: 1e10 rows over 8 GPUs = 1.25e9 rows per GPU; a pass takes ~0.25 s, so the default
         # run keeps the full per-GPU size but caps the step count
