@@ -68,16 +68,45 @@ def pmc_source(kernels, default_shape):
     return None
 
 
+def visible_gpus(base="/sys/class/kfd/kfd/topology/nodes"):
+    """GPUs this process may use, counted WITHOUT touching HIP: torch.cuda.device_count() falls back
+    to hipGetDeviceCount when amdsmi is not importable, which initialises the runtime in the
+    launcher.  HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES if set, else the
+    KFD topology: nodes with simd_count > 0 are GPUs (CPUs have simd_count 0)."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([t for t in v.split(",") if t.strip() != ""])
+    n = 0
+    try:
+        for node in os.listdir(base):
+            try:
+                with open(os.path.join(base, node, "properties")) as fh:
+                    props = dict(ln.split()[:2] for ln in fh if len(ln.split()) >= 2)
+                if int(props.get("simd_count", "0")) > 0:
+                    n += 1
+            except (OSError, ValueError):
+                continue
+    except OSError:
+        return None                 # no KFD here: let the ranks fail loudly instead
+    return n
+
+
 def launch_ranks(ngpus, argv):
-    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: this process (which has not
-    touched the GPU -- counting devices does not initialise HIP) starts N fresh child processes, one
-    per device, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, relays rank 0's JSON line and
-    exits with the worst child status.  Nothing is exec'ed from a process that has initialised HIP."""
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: this process, which never
+    touches the GPU (devices are counted from the environment or the KFD topology files, not
+    through HIP), starts N fresh child processes, one per device, with RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* set, relays rank 0's JSON line and exits with the worst child status.
+    Nothing is exec'ed from a process that has initialised HIP.  PROFILING IS DONE PER RANK: put
+    the single-rank program directly after `rocprofv3 ... --` (with RANK/WORLD_SIZE/MASTER_* in the
+    environment for N > 1), never this self-launcher -- the profiler's preloaded library
+    initialises the GPU in the launcher, and its children would then be started from a
+    GPU-initialised process."""
     import socket
     import subprocess
     rehearsal = bool(os.environ.get("WM_BENCH_REHEARSAL"))
-    ndev = torch.cuda.device_count()
-    if ndev < ngpus and not rehearsal and "plumbing" not in argv:
+    ndev = visible_gpus()
+    if ndev is not None and ndev < ngpus and not rehearsal and "plumbing" not in argv:
         raise SystemExit(f"bench.py --gpus {ngpus}: only {ndev} GPU(s) visible "
                          f"(WM_BENCH_REHEARSAL=1 runs all ranks on GPU 0 over gloo)")
     with socket.socket() as sk:

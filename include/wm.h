@@ -89,7 +89,10 @@ int wm_conv2d_bwd_wb_f32(const float *x, const float *gy, float *gw, float *gb,
  * (wm_conv2d_bwd_wb_workspace_bytes(...) > wm_conv2d_bwd_wb_noalloc_max_bytes()) are rejected
  * with WM_ERR_UNSUPPORTED.  The call allocates and frees nothing.  Results are bitwise those of
  * wm_conv2d_bwd_wb_f32.  All calls on one GPU share that GPU's array: calls that overlap on one
- * GPU (different streams or threads) race -- serialise them. */
+ * GPU (different streams or threads) race -- serialise them.  The device that owns `stream` must be
+ * the current device (WM_ERR_INVALID otherwise: each GPU has its own array).  The first call per
+ * device and shape makes host-side queries (the array's address, an occupancy query): make it once
+ * before a stream capture begins. */
 #define WM_CONV2D_NOALLOC_SCRATCH_BYTES (1u << 20)
 size_t wm_conv2d_bwd_wb_noalloc_max_bytes(void);
 int wm_conv2d_bwd_wb_noalloc_f32(const float *x, const float *gy, float *gw, float *gb,
@@ -289,8 +292,10 @@ int wm_gather_cubes_strided_f32(const float *vol, int files, int nvars, int Z, i
  * otherwise), all tensors 16-byte aligned.
  * wm_dense_bwd_f32: gx (M, K) = gy W, masked where mask_below <= 0 when mask_below != NULL (the
  * post-ReLU activation that fed this layer, i.e. x itself: the ReLU backward of the layer below
- * fused into the store); gW (N, K) = gy^T x; gb (N) = column sums of gy.  gx or gW (with gb) may be
- * NULL to skip that part.  The workspace holds the split partial sums of gx. */
+ * fused into the store); gW (N, K) = gy^T x; gb (N) = column sums of gy.  gx may be NULL, or gW
+ * together with gb, to skip that part; gb is formed by the weight-gradient pass, so gb without gW
+ * and a call with neither gx nor gW are rejected (WM_ERR_INVALID).  The workspace holds the split
+ * partial sums of gx. */
 int wm_dense_fwd_f32(const float *x, const float *W, const float *b, float *y, int M, int N, int K,
                      int relu, void *stream);
 size_t wm_dense_bwd_workspace_bytes(int M, int N, int K);
@@ -305,11 +310,37 @@ int wm_dense_bwd_f32(const float *x, const float *W, const float *gy, const floa
  * target of the batch -- what the reference's (B, 1, P) targets do to the (B, P) predictions
  * (SURVEY.md 2b); broadcast == 0 pairs row i with row i.  out3 = {mean (y-p)^2, mean |y-p|,
  * mean (log1p(max(p,eps)) - log1p(max(y,eps)))^2} (device memory, 3 floats); grad (may be NULL) is
- * d out3[0] / d pred, shape (B, P).  B <= 4096.  Sums are float64 in a fixed order. */
+ * d out3[0] / d pred, shape (B, P).  B <= 4096.  A thread sums its pair terms in float32 over
+ * blocks of at most 64 targets (the gradient's target sum in float64 term by term); blocks, threads
+ * and workgroups are combined in float64 in a fixed order. */
 size_t wm_mse_metrics_workspace_bytes(int64_t P);
 int wm_mse_metrics_f32(const float *pred, const float *y, int B, int64_t P, int broadcast,
                        float eps, float *grad, float *out3, void *workspace,
                        size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------ exchange step ------- */
+
+/* The one collective of the data-parallel path (SURVEY.md 8b ABI block, 8e) for hosts without
+ * torch.distributed: rows / samples are sharded over one process per GPU, and between wm_gram_f32
+ * and wm_normal_solve_f64 (the float64 Gram `acc`) or between wm_model_train_f32 and
+ * wm_adam_step_f32 (the flat float32 gradient) every rank sums ONE flat buffer in place.  The
+ * reference has no counterpart (its MirroredStrategy, singleRegression.py:488-496, is dead code).
+ * RCCL (librccl.so, opened with dlopen at the first call: WM_ERR_UNSUPPORTED if absent) over xGMI;
+ * one communicator per process, bound to the device current at wm_comm_init.
+ *   wm_comm_unique_id  rank 0 fills WM_COMM_ID_BYTES of HOST memory; ship them to every rank
+ *                      (file, socket, environment) -- the library does no rendezvous of its own;
+ *   wm_comm_init       collective over the nranks processes; the current device is this rank's GPU;
+ *   wm_allreduce_sum   buf (device, count elements of WM_F32 / WM_F64) <- sum over ranks, in place,
+ *                      asynchronous on `stream`; one call per step on the whole buffer;
+ *   wm_comm_size       ranks of the live communicator, 0 if none;  wm_comm_destroy  frees it. */
+#define WM_COMM_ID_BYTES 128
+#define WM_F32 0
+#define WM_F64 1
+int wm_comm_unique_id(void *id128);
+int wm_comm_init(int rank, int nranks, const void *unique_id);
+int wm_comm_size(void);
+int wm_allreduce_sum(void *buf, size_t count, int dtype, void *stream);
+int wm_comm_destroy(void);
 
 /* ------------------------------------------------------------------ synthetic data ------ */
 

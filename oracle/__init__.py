@@ -8,4 +8,6 @@ library is missing.
                           fwd / bwd-data / bwd-weight+bias, Gram, normal-equation solve).
 * ``oracle.model_ref`` -- numpy float64 restatement of ``newConvolution.CustomModel``
                           (forward, backward, MSE, Adam), reference newConvolution.py:109-186.
+* ``oracle.generators`` -- numpy restatement of ``WeatherDataGenerator`` (rows, cubes, region
+                          walk), reference multipleRegression.py:217-270; arbitrates row a9.
 """

@@ -76,3 +76,19 @@ def test_product_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in text and "from oracle" not in text, f
                 assert "libwm_oracle" not in text, f
+
+
+def test_exchange_entry_points_refuse_use_without_a_communicator():
+    """wm_comm_* (the C-ABI exchange step): argument checks and the no-communicator state are
+    checkable without a GPU; librccl is only opened by the calls that need it."""
+    from weather_model_amd import _lib
+    L = _lib.lib()
+    assert L.wm_comm_size() == 0
+    assert L.wm_allreduce_sum(0, 0, 7, 0) == -1 and b"dtype" in L.wm_last_error()
+    assert L.wm_allreduce_sum(0, 4, 0, 0) == -1 and b"null buffer" in L.wm_last_error()
+    buf = ctypes.create_string_buffer(64)
+    assert L.wm_allreduce_sum(ctypes.cast(buf, ctypes.c_void_p), 4, 0, 0) == -1
+    assert b"no communicator" in L.wm_last_error()
+    assert L.wm_comm_init(2, 2, ctypes.cast(buf, ctypes.c_void_p)) == -1      # rank outside world
+    assert L.wm_comm_init(0, 1, 0) == -1
+    assert L.wm_comm_destroy() == 0                                           # nothing to destroy

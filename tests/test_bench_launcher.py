@@ -38,3 +38,26 @@ def test_gpu_workload_without_gpu_fails_loudly():
     r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--workload", "gram16"])
     assert r.returncode != 0
     assert "GPU" in r.stderr
+
+
+def test_launcher_counts_gpus_without_hip(tmp_path, monkeypatch):
+    """The launcher parent must never touch the GPU: devices come from the *_VISIBLE_DEVICES
+    variables or from the KFD topology files (GPU nodes have simd_count > 0), not from
+    torch.cuda.device_count(), which initialises HIP when amdsmi is absent."""
+    sys.path.insert(0, ROOT)
+    import bench
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    for k, simd in enumerate((0, 0, 1024, 1024, 1024)):          # two CPU nodes, three GPUs
+        d = tmp_path / str(k)
+        d.mkdir()
+        (d / "properties").write_text(f"cpu_cores_count {16 if simd == 0 else 0}\nsimd_count {simd}\n")
+    assert bench.visible_gpus(str(tmp_path)) == 3
+    assert bench.visible_gpus(str(tmp_path / "missing")) is None
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1")
+    assert bench.visible_gpus(str(tmp_path)) == 2
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
+    assert bench.visible_gpus(str(tmp_path)) == 0
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    launcher = src[src.index("def launch_ranks"):src.index("def dist_setup")]
+    assert "torch.cuda" not in launcher

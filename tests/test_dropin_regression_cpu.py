@@ -163,6 +163,41 @@ def test_multiple_regression_generator_rows():
     assert start == 12
 
 
+def test_oracle_walk_is_what_the_host_generator_yields():
+    """oracle/generators.py (the literal restatement of multipleRegression.py:217-270 that arbitrates
+    the device row builder) against the drop-in's generator, over enough batches for the second
+    and third region coordinates to move (they lag one and two batches behind the first), and
+    resumed from a saved state."""
+    from oracle import generators as ogen
+    mr = _mr(n_files=64, shape=(1, 3, 4, 5))
+    stats = [mr.DATA_VARS_MIN, mr.DATA_VARS_MAX, mr.DATA_VARS_MEAN, mr.DATA_VARS_STD]
+    all_data = mr.load_data(64, 0, stats)
+    it = 1
+    var = [d for d in mr.DATA_VARS if mr.VARIABLE_TEST[it][d]]
+    data_dim = (1, 3, 4, 5)                              # every cell of the (3, 4, 5) field
+    length = 2
+    gen = mr.WeatherDataGenerator(64, (1, 1, 1, 1), length, data_dim, it, all_data, 0, stats)
+    count = length * 3 * 4 * 2 + 5                       # R0 passes 3 * 4: R1 and R2 move
+    x1, x2, y = gen.rows(count)
+    (o1, o2, oy), state = ogen.walk(all_data, 0, var, 1, mr.BATCH_SIZE[it], mr.TIME_SPAN, length,
+                                    data_dim, count)
+    np.testing.assert_array_equal(o1, x1)
+    np.testing.assert_array_equal(o2, x2)
+    np.testing.assert_array_equal(oy, y)
+    assert state == gen.get_state() and state[1][1] >= 1 and state[1][2] >= 1
+    # literal check of the first batches against plain indexing: region (R0 % 3, R1 % 4, R2 % 5)
+    b = mr.BATCH_SIZE[it]
+    for k, reg in ((0, (0, 0, 0)), (2, (1, 0, 0)), (2 * 3, (0, 0, 0)), (2 * 3 + 1, (0, 1, 0))):
+        r = k * b
+        f = (k % length) * b
+        assert o1[r, 0, 0, 0, 0] == all_data[f][var[0]][0][reg]
+        assert o2[r, 0, 0, 0, 0] == all_data[f + mr.TIME_SPAN][var[0]][0][reg]
+    (p1, _, _), st2 = ogen.walk(all_data, 0, var, 1, b, mr.TIME_SPAN, length, data_dim, 3, state=state)
+    q1, _, _ = gen.rows(3)
+    np.testing.assert_array_equal(p1, q1)
+    assert st2 == gen.get_state()
+
+
 def test_regression_models_need_the_gpu_library():
     """No CPU fallback: without a GPU the compute calls raise instead of answering."""
     import torch

@@ -1,6 +1,8 @@
 """GPU tests of the assembled Conv3D network (convolution.create_model) against a plain torch-CPU
-restatement with the same weights: forward, loss, every parameter gradient (1e-4 relative in
-max-norm: both sides are float32 end to end), training behaviour and the Keras-surface details."""
+restatement with the same weights evaluated in FLOAT64: forward, loss, every parameter gradient
+(1e-5 in ||a-b||inf / ||b||inf, the conv tolerance of BASELINE.json), training behaviour and the
+Keras-surface details.  Parity unpinned: keras/tensorflow, where the reference's network lives, are
+absent, so the arbiter is the operator definition as torch-CPU float64 evaluates it."""
 import importlib
 import os
 import sys
@@ -69,19 +71,20 @@ def test_forward_and_gradients_match_torch_cpu(channels_last):
     x1 = synth.uniform(21, (B, 1, 20, 20, 20))
     x2 = synth.uniform(22, (B, 1, 20, 20, 20))
     y = synth.uniform(23, (B, 1, 8000))
-    P = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.params.items()}
-    ref = _cpu_forward(P, torch.from_numpy(x1), torch.from_numpy(x2), channels_last)
+    # the arbiter runs in float64 on the same float32 values
+    P = {k: v.detach().cpu().double().requires_grad_(True) for k, v in m.params.items()}
+    ref = _cpu_forward(P, torch.from_numpy(x1).double(), torch.from_numpy(x2).double(), channels_last)
     got = m([x1, x2], training=True)
-    assert relinf(got.detach().cpu().numpy(), ref.detach().numpy()) < 1e-4
+    assert relinf(got.detach().cpu().numpy(), ref.detach().numpy()) < 1e-5
     yt = torch.from_numpy(y)
-    ref_loss = ((yt - ref) ** 2).mean()        # (B,1,P) - (B,P) broadcasts to (B,B,P)
-    assert ((yt - ref) ** 2).shape == (B, B, 8000)
+    ref_loss = ((yt.double() - ref) ** 2).mean()        # (B,1,P) - (B,P) broadcasts to (B,B,P)
+    assert ((yt.double() - ref) ** 2).shape == (B, B, 8000)
     loss = m.loss_fn(got, yt.cuda())
     assert float(loss) == pytest.approx(float(ref_loss), rel=1e-5)
     ref_loss.backward()
     loss.backward()
     for k, v in m.params.items():
-        assert relinf(v.grad.cpu().numpy(), P[k].grad.numpy()) < 1e-4, k
+        assert relinf(v.grad.cpu().numpy(), P[k].grad.numpy()) < 1e-5, k
 
 
 def test_training_reduces_loss_and_early_stopping():
@@ -215,7 +218,8 @@ def test_data_generator_device_batches_bit_exact():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,P,broadcast", [(16, 8000, True), (5, 37, True), (33, 1000, True),
-                                           (64, 130, True), (16, 8000, False), (1, 3, True), (200, 24, True)])
+                                           (64, 130, True), (16, 8000, False), (1, 3, True), (200, 24, True),
+                                           (4096, 6, True), (4096, 5, False), (1000, 17, True)])
 def test_fused_loss_metrics_and_gradient(B, P, broadcast):
     """wm_mse_metrics_f32 against the tensor expressions of the model (keras' mean_squared_error
     on (B,1,P) targets, mae, msle with the epsilon clip) and autograd's gradient, in float64."""
@@ -223,6 +227,10 @@ def test_fused_loss_metrics_and_gradient(B, P, broadcast):
     gen = torch.Generator().manual_seed(B * 1000 + P)
     pred = (torch.rand((B, P), generator=gen) * 2.0 - 0.5)       # some values below the clip
     y = torch.rand((B, P), generator=gen) * 1.5 - 0.25
+    if B >= 1000:
+        # the documented batch limit: predictions near the batch mean of the targets, where the
+        # gradient B*p - sum(y) cancels (float32 sums over the batch lose it: ADVICE r2)
+        pred = y.mean(0, keepdim=True) + 1e-3 * (torch.rand((B, P), generator=gen) - 0.5)
     out3, grad = ops.mse_metrics(pred.cuda(), y.cuda(), broadcast)
     pd = pred.double().requires_grad_(True)
     yd = y.double()
@@ -266,6 +274,18 @@ def test_dense_layers_match_float64(M, K, N):
     assert relinf(out.detach().cpu().numpy(), outr.detach().numpy()) < 1e-5
     for a, r, name in zip(leaves, ref, ("x", "W1", "b1", "W2", "b2")):
         assert relinf(a.grad.cpu().numpy(), r.grad.numpy()) < 1e-5, name
+    # the contract of include/wm.h: the bias gradient rides on the weight-gradient pass
+    from weather_model_amd import _lib
+    L = _lib.lib()
+    xs, gs, Ws = leaves[0].detach(), g.cuda(), leaves[1].detach()
+    if M == 16 and N == 640:
+        gbuf = torch.empty(N, device="cuda")
+        st = torch.cuda.current_stream().cuda_stream
+        rc = L.wm_dense_bwd_f32(xs.data_ptr(), Ws.data_ptr(), gs.data_ptr(), 0, 0, 0, gbuf.data_ptr(),
+                                0, 0, M, N, K, st)
+        assert rc == -1 and b"needs gW" in L.wm_last_error()
+        rc = L.wm_dense_bwd_f32(xs.data_ptr(), Ws.data_ptr(), gs.data_ptr(), 0, 0, 0, 0, 0, 0, M, N, K, st)
+        assert rc == -1 and b"neither" in L.wm_last_error()
     # the stand-alone form: ReLU backward applied by the layer itself
     l2 = [t.cuda().requires_grad_(True) for t in (x, W1, b1)]
     ops.dense(l2[0], l2[1], l2[2], relu=True).backward(torch.ones((M, K), device="cuda"))

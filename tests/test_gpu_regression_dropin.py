@@ -178,9 +178,11 @@ def test_fit_streams_many_chunks():
 
 
 def test_device_rows_bit_exact_vs_host_generator():
-    """Row a9: wm_gather_cubes_f32's closed-form region walk against the drop-in's host generator
-    (the literal update rule of multipleRegression.py:259-270), bit for bit, over enough batches
-    for all three region coordinates to move; then with 2^3 cubes of three variables."""
+    """Row a9: wm_gather_cubes_f32's closed-form region walk against oracle/generators.py (the
+    literal restatement of multipleRegression.py:217-270) AND the drop-in's host generator, bit for
+    bit, over enough batches for all three region coordinates to move; then with 2^3 cubes of
+    three variables."""
+    from oracle import generators as ogen
     n_files = 120
     mr = _mr(n_files, (1, 12, 14, 14))
     stats = [mr.DATA_VARS_MIN, mr.DATA_VARS_MAX, mr.DATA_VARS_MEAN, mr.DATA_VARS_STD]
@@ -200,26 +202,36 @@ def test_device_rows_bit_exact_vs_host_generator():
         count = 9 * length + 3                   # region_index reaches (9, 4, 2): all three move
         x1, x2, y = host.rows(count)
         Xh = np.concatenate([x1.reshape(len(x1), -1), x2.reshape(len(x2), -1)], axis=1)
+        # the arbiter: the oracle's walk over the same fields, from the same start state
+        tested_in_order = [d for d in mr.DATA_VARS if d in tested]
+        (o1, o2, oy), ostate = ogen.walk(all_data, start, tested_in_order, cube, bs, mr.TIME_SPAN,
+                                         length, data_dim, count)
+        Xo = np.concatenate([o1.reshape(len(o1), -1), o2.reshape(len(o2), -1)], axis=1)
+        assert np.array_equal(Xo, Xh) and np.array_equal(oy, y)       # the host generator follows it
         # in three uneven pieces: the walk must resume from the saved state
         parts = [dev.device_rows(k) for k in (5, length + 1, count - length - 6)]
         Xd = torch.cat([p[0] for p in parts]).cpu().numpy()
         Yd = torch.cat([p[1] for p in parts]).cpu().numpy()
         assert Xd.shape == Xh.shape == (count * bs, 2 * len(tested) * cube ** 3)
-        assert np.array_equal(Xd, Xh.astype(np.float32))
-        assert np.array_equal(Yd, y.astype(np.float32))
+        assert np.array_equal(Xd, Xo.astype(np.float32))
+        assert np.array_equal(Yd, oy.astype(np.float32))
         assert dev.get_state() == host.get_state()
+        assert tuple(dev.get_state()[1]) == tuple(ostate[1]) and dev.get_state()[0] == ostate[0]
         assert host.region_index[0] >= 9 and host.region_index[1] >= 1
         # a generator state beyond 2^31 batches: the kernel's 64-bit walk (the run above took
         # the 31-bit fast path)
         far = (2 ** 31 + 7, ((2 ** 31 + 7) // length, 2 ** 31 + 1, 5))
         host.set_state(far)
         dev.set_state(far)
-        x1, x2, y = host.rows(length + 2)
-        Xh = np.concatenate([x1.reshape(len(x1), -1), x2.reshape(len(x2), -1)], axis=1)
+        (o1, o2, oy), ostate = ogen.walk(all_data, start, tested_in_order, cube, bs, mr.TIME_SPAN,
+                                         length, data_dim, length + 2, state=far)
+        Xo = np.concatenate([o1.reshape(len(o1), -1), o2.reshape(len(o2), -1)], axis=1)
+        host.rows(length + 2)
         Xd, Yd = dev.device_rows(length + 2)
-        assert np.array_equal(Xd.cpu().numpy(), Xh.astype(np.float32))
-        assert np.array_equal(Yd.cpu().numpy(), y.astype(np.float32))
+        assert np.array_equal(Xd.cpu().numpy(), Xo.astype(np.float32))
+        assert np.array_equal(Yd.cpu().numpy(), oy.astype(np.float32))
         assert dev.get_state() == host.get_state()
+        assert tuple(dev.get_state()[1]) == tuple(ostate[1]) and dev.get_state()[0] == ostate[0]
 
 
 def test_gather_cubes_explicit_origins_and_errors():

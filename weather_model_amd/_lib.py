@@ -58,6 +58,11 @@ SIGNATURES = {
     "wm_dense_bwd_f32": (c_int, [vp, vp, vp, vp, vp, vp, vp, vp, c_sz, c_int, c_int, c_int, vp]),
     "wm_mse_metrics_workspace_bytes": (c_sz, [c_i64]),
     "wm_mse_metrics_f32": (c_int, [vp, vp, c_int, c_i64, c_int, c_f32, vp, vp, vp, c_sz, vp]),
+    "wm_comm_unique_id": (c_int, [vp]),
+    "wm_comm_init": (c_int, [c_int, c_int, vp]),
+    "wm_comm_size": (c_int, []),
+    "wm_allreduce_sum": (c_int, [vp, c_sz, c_int, vp]),
+    "wm_comm_destroy": (c_int, []),
     "wm_synth_uniform_f32": (c_int, [vp, c_i64, c_u64, c_u64, c_f32, c_f32, vp]),
     "wm_synth_regression_f32": (c_int, [vp, vp, c_i64, c_int, c_int, c_u64, c_u64, vp, c_f32,
                                         c_f32, c_int, vp]),

@@ -41,6 +41,7 @@ def _compile(src, extra=()):
         return obj
     cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall",
            "-Wno-unused-function", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
+           "-I", "/opt/rocm/include",
            *extra, "-c", os.path.join(CSRC, src), "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
@@ -58,7 +59,7 @@ def build(force: bool = False, jobs: int = 4) -> str:
     with concurrent.futures.ThreadPoolExecutor(max_workers=jobs) as ex:
         objs = list(ex.map(_compile, sources()))
     if force or _stale(LIB, objs):
-        cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs]
+        cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")

@@ -17,7 +17,9 @@
 // caller's workspace -> a fixed-order float64 finalize kernel (bitwise reproducible).
 #include "common.h"
 
+#include <map>
 #include <mutex>
+#include <tuple>
 
 namespace {
 
@@ -999,25 +1001,22 @@ __global__ __launch_bounds__(BLOCK) void conv_bwd_wb_generic_kernel(
 
 // hipOccupancyMaxActiveBlocksPerMultiprocessor is a host-side query of a few microseconds and is
 // not legal under stream capture: ask once per (device, kernel, block size) and keep the answer.
+// (a map under a mutex: a fixed table that fills up would redo the query on every call)
 template <typename K>
 int cached_occupancy(K kernel, int block, int *out)
 {
-    struct Slot { const void *fn; int block; int occ; };
     static std::mutex mu;
-    static Slot slots[64][48] = {};
+    static std::map<std::tuple<int, const void *, int>, int> cache;
     int dev = 0;
     WM_HIP(hipGetDevice(&dev));
-    WM_REQUIRE(dev >= 0 && dev < 64, WM_ERR_NO_DEVICE, "device index %d out of range", dev);
     const void *fn = reinterpret_cast<const void *>(kernel);
     std::lock_guard<std::mutex> lock(mu);
-    Slot *free_slot = nullptr;
-    for (Slot &s : slots[dev]) {
-        if (s.fn == fn && s.block == block) { *out = s.occ; return WM_OK; }
-        if (s.fn == nullptr && !free_slot) free_slot = &s;
-    }
+    const auto key = std::make_tuple(dev, fn, block);
+    const auto hit = cache.find(key);
+    if (hit != cache.end()) { *out = hit->second; return WM_OK; }
     int occ = 0;
     WM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, block, 0));
-    if (free_slot) { free_slot->fn = fn; free_slot->block = block; free_slot->occ = occ; }
+    cache[key] = occ;
     *out = occ;
     return WM_OK;
 }
@@ -1463,6 +1462,17 @@ extern "C" int wm_conv2d_bwd_wb_noalloc_f32(const float *x, const float *gy, flo
                "wm_conv2d_bwd_wb_noalloc_f32: this shape needs %zu bytes of partial sums, the "
                "static scratch holds %zu -- use wm_conv2d_bwd_wb_f32 with a caller workspace",
                need, SCRATCH_BYTES);
+    // every GPU holds its own copy of the scratch array, and scratch_ptr() hands out the CURRENT
+    // device's: a stream that belongs to another device would get this device's array
+    if (stream) {
+        int cur = 0, sdev = 0;
+        WM_HIP(hipGetDevice(&cur));
+        WM_HIP(hipStreamGetDevice((hipStream_t)stream, &sdev));
+        WM_REQUIRE(cur == sdev, WM_ERR_INVALID,
+                   "wm_conv2d_bwd_wb_noalloc_f32: the stream belongs to device %d but device %d is "
+                   "current -- make the stream's device current (hipSetDevice) before the call",
+                   sdev, cur);
+    }
     void *ptr = nullptr;
     if (int rc = scratch_ptr(&ptr)) return rc;
     return wm_conv2d_bwd_wb_f32(x, gy, gw, gb, ptr, SCRATCH_BYTES, N, Cin, H, W, Cout, kH, kW,

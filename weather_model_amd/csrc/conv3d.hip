@@ -15,7 +15,9 @@
 // partials and combined in a fixed order (bitwise reproducible, no atomics).
 #include "common.h"
 #include <cstdlib>
+#include <map>
 #include <mutex>
+#include <tuple>
 #include <type_traits>
 
 namespace {
@@ -2136,24 +2138,24 @@ wb_vol_fn wb_vol_kernel(int otiles, int ktw)
 // capture.  Also raises the kernel's dynamic-LDS limit when it needs more than 64 KB.  0: failed.
 int occupancy_cached(const void *fn, size_t lds)
 {
-    struct Slot { const void *fn; size_t lds; int occ; };
+    // a map, not a fixed table: the row, staged and forward kernels have more than 40 template
+    // variants and the LDS part of the key depends on the shape -- a full table silently fell back
+    // to the query on every call, which is not legal under stream capture
     static std::mutex mu;
-    static Slot slots[64][24] = {};
+    static std::map<std::tuple<int, const void *, size_t>, int> cache;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) return 0;
     std::lock_guard<std::mutex> lock(mu);
-    Slot *slot = nullptr;
-    for (Slot &c : slots[dev]) {
-        if (c.fn == fn && c.lds == lds) return c.occ;
-        if (!c.fn && !slot) slot = &c;
-    }
+    const auto key = std::make_tuple(dev, fn, lds);
+    const auto hit = cache.find(key);
+    if (hit != cache.end()) return hit->second;
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return 0;
     int occ = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, BLOCK, lds) != hipSuccess || occ <= 0)
         return 0;
-    if (slot) { slot->fn = fn; slot->lds = lds; slot->occ = occ; }
+    cache[key] = occ;
     return occ;
 }
 

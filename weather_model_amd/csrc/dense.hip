@@ -249,6 +249,9 @@ extern "C" int wm_dense_bwd_f32(const float *x, const float *W, const float *gy,
                                 void *stream)
 {
     WM_REQUIRE(x && W && gy, WM_ERR_INVALID, "wm_dense_bwd_f32: null pointer");
+    WM_REQUIRE(!(gb && !gW), WM_ERR_INVALID,
+               "wm_dense_bwd_f32: gb is formed by the weight-gradient pass and needs gW");
+    WM_REQUIRE(gx || gW, WM_ERR_INVALID, "wm_dense_bwd_f32: neither gx nor gW requested");
     if (int rc = check_dense("wm_dense_bwd_f32", M, N, K)) return rc;
     WM_REQUIRE(aligned16(x) && aligned16(W) && aligned16(gy) && aligned16(gx) && aligned16(gW) &&
                    aligned16(mask_below) && aligned16(workspace),

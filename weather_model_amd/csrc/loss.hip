@@ -8,14 +8,18 @@
 //   msle = mean (log1p(max(p_i, eps)) - log1p(max(y_j, eps)))^2,
 //   grad[i] = d loss / d p_i = 2 / (pairs * P) * sum_j (p_i - y_j)
 // Framework glue takes ~20 element-wise launches over the (B, B, P) differences for this (90 us of a
-// 560 us step at batch 16); here one pass.  Sums are float32 per thread (<= B terms), float64 from
-// there on, combined in a fixed order (bitwise reproducible).
+// 560 us step at batch 16); here one pass.  A thread sums its (non-negative) pair terms in float32
+// over blocks of at most 64 targets and folds the blocks in float64; the target sum of the
+// gradient, B*p - sum(y), which cancels when p is near the batch mean of y, is float64 term by
+// term (float32 blocks of 64 left 2e-5 of the gradient at B = 4096); float64 from there on,
+// combined in a fixed order (bitwise reproducible).
 #include "common.h"
 
 namespace {
 
 constexpr int BLOCK = 256;
-constexpr int MAXB = 4096;        // float32 pair sums per thread stay short
+constexpr int MAXB = 4096;
+constexpr int JBLOCK = 64;        // float32 pair sums per thread stay this short
 
 // One thread per prediction (i, p): it walks the targets y[j][p] it is scored against (all B rows
 // with `broadcast`, row i otherwise) -- the p of a wave are consecutive, so every load is
@@ -35,21 +39,25 @@ __global__ __launch_bounds__(BLOCK) void mse_metrics_kernel(const float *__restr
         const long long i = e / P, p = e - i * P;
         const float pv = pred[e];
         const float lp = log1pf(fmaxf(pv, eps));
-        float s2 = 0.0f, s1 = 0.0f, sl = 0.0f, ysum = 0.0f;
         const int j0 = broadcast ? 0 : (int)i, j1 = broadcast ? B : (int)i + 1;
+        double ysum = 0.0;
+        for (int jb = j0; jb < j1; jb += JBLOCK) {
+            const int je = jb + JBLOCK < j1 ? jb + JBLOCK : j1;
+            float s2 = 0.0f, s1 = 0.0f, sl = 0.0f;
 #pragma unroll 8
-        for (int j = j0; j < j1; ++j) {
-            const float yv = y[(long long)j * P + p];
-            const float d = yv - pv, q = lp - log1pf(fmaxf(yv, eps));
-            s2 = fmaf(d, d, s2);
-            s1 += fabsf(d);
-            sl = fmaf(q, q, sl);
-            ysum += yv;
+            for (int j = jb; j < je; ++j) {
+                const float yv = y[(long long)j * P + p];
+                const float d = yv - pv, q = lp - log1pf(fmaxf(yv, eps));
+                s2 = fmaf(d, d, s2);
+                s1 += fabsf(d);
+                sl = fmaf(q, q, sl);
+                ysum += (double)yv;          // every term in float64: B*p - sum(y) cancels
+            }
+            se += (double)s2;
+            ae += (double)s1;
+            le += (double)sl;
         }
-        if (grad) grad[e] = gscale * ((float)(j1 - j0) * pv - ysum);
-        se += (double)s2;
-        ae += (double)s1;
-        le += (double)sl;
+        if (grad) grad[e] = (float)((double)gscale * ((double)(j1 - j0) * (double)pv - ysum));
     }
     se = wave_sum(se);
     ae = wave_sum(ae);
