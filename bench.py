@@ -240,6 +240,36 @@ def timed_steps(step, steps, warmup, world, cuda=True):
     return max_over_ranks(t1 - t0, world)
 
 
+class Exchange:
+    """The data-parallel exchange step of a workload, with HIP events around it on every fourth
+    timed step (`exchange_us` in the JSON line: what the all-reduce costs on the stream, so that a
+    scaling run explains its own efficiency).  No-op at N = 1."""
+
+    def __init__(self, world):
+        self.world = world
+        self.ev = []
+        self.calls = 0
+
+    def run(self, fn, timed=True):
+        if self.world == 1:
+            return
+        self.calls += 1
+        if timed and self.calls % 4 == 1:
+            e = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            e[0].record()
+            fn()
+            e[1].record()
+            self.ev.append(e)
+        else:
+            fn()
+
+    def us(self):
+        if not self.ev:
+            return None
+        torch.cuda.synchronize()
+        return float(np.mean([a.elapsed_time(b) for a, b in self.ev])) * 1e3
+
+
 # ------------------------------------------------------------------------------ regression
 def gram_cpu_baselines(X, Y, F, P, beta_gpu):
     """CPU legs beside the Gram numbers (rank 0, N = 1): `cpu_baseline` = the library path the
@@ -324,6 +354,7 @@ def run_gram(F, n_rows, steps, warmup, rank, world, cpu_base, P=1, dist="uniform
     plan = ops.GramPlan(n_rows, F, P, "cuda")
 
     evs, sevs = [], []
+    xch = Exchange(world)
 
     def step(i, timed):
         plan.acc.zero_()
@@ -336,8 +367,7 @@ def run_gram(F, n_rows, steps, warmup, rank, world, cpu_base, P=1, dist="uniform
         plan.accumulate(X, Y)
         if timed:
             e[1].record()
-        if world > 1:
-            dp.reduce_gram_(plan.acc)            # the one exchange step: (F+1+P)^2 float64
+        xch.run(lambda: dp.reduce_gram_(plan.acc), timed)   # the one exchange step: (F+1+P)^2 float64
         plan.solve()
         if timed:
             if world == 1:
@@ -358,6 +388,7 @@ def run_gram(F, n_rows, steps, warmup, rank, world, cpu_base, P=1, dist="uniform
         "ms_per_step": total / steps * 1e3,
         "planted_coef_max_err": err,
         "kernel_ms_avg": kavg * 1e3,
+        "exchange_us": xch.us(),
     }
     if sevs:
         res["solve_ms_avg"] = float(np.mean([a.elapsed_time(c) for a, c in sevs]))
@@ -414,6 +445,7 @@ def run_gram64(steps, warmup, rank, world, cpu_base, rows_per_gpu, chunk_rows=50
     row_off = rank * rows_per_gpu
     kern_ms = []
     pending = []
+    xch = Exchange(world)
 
     def step(i, timed):
         st = torch.cuda.current_stream().cuda_stream
@@ -430,8 +462,7 @@ def run_gram64(steps, warmup, rank, world, cpu_base, rows_per_gpu, chunk_rows=50
             if timed:
                 e[1].record()
                 pending.append((e, m))
-        if world > 1:
-            dp.reduce_gram_(plan.acc)            # the one exchange step: 66x66 float64
+        xch.run(lambda: dp.reduce_gram_(plan.acc), timed)   # the one exchange step: 66x66 float64
         plan.solve()
 
     total = timed_steps(step, steps, warmup, world)
@@ -449,6 +480,7 @@ def run_gram64(steps, warmup, rank, world, cpu_base, rows_per_gpu, chunk_rows=50
         "ms_per_step": total / steps * 1e3,
         "kernel_rows_per_s": krate, "kernel_ms_per_chunk": kern_s / len(pending) * 1e3,
         "end_to_end_rows_per_s_per_gpu": rows_per_gpu * steps / total,
+        "exchange_us": xch.us(),
         "planted_coef_rel_err": err,
         "config": {"workload": f"multipleRegression least squares F=64, P=1, {rows_per_gpu} rows "
                                f"per GPU generated on the device in {nchunks} resident chunks of "
@@ -495,6 +527,7 @@ def run_conv(steps, warmup, rank, world, cpu_base, N=64, H=721, W=1440):
     grads = torch.zeros((10,), device="cuda")
     fwd_ev, bwd_ev = [], []
     pair_ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    xch = Exchange(world)
 
     def launch_pair(k, st, ef=False, eb=False):
         if ef:
@@ -531,7 +564,7 @@ def run_conv(steps, warmup, rank, world, cpu_base, N=64, H=721, W=1440):
             return
         mod = 4 if steps >= 8 else (2 if steps >= 2 else 1)
         launch_pair(k, st, ev and i % mod == 0, ev and i % mod == mod // 2)
-        dp.reduce_grads_(grads)              # DP weight-gradient exchange (10 floats)
+        xch.run(lambda: dp.reduce_grads_(grads), ev)     # DP weight-gradient exchange (10 floats)
 
     total = timed_steps(step, steps, warmup, world)
     pts = N * H * W
@@ -554,7 +587,7 @@ def run_conv(steps, warmup, rank, world, cpu_base, N=64, H=721, W=1440):
     res = {
         "value": pts * world * steps / total, "unit": "grid-pts/s", "ms_per_step": total / steps * 1e3,
         "config": {"workload": "conv 3x3 C=1 fwd+bwd(weight,bias), 721x1440 grid, batch 64 per GPU"},
-        "fwd_ms": fwd_ms, "bwd_wb_ms": bwd_ms, "pair_ms": pair_ms,
+        "fwd_ms": fwd_ms, "bwd_wb_ms": bwd_ms, "pair_ms": pair_ms, "exchange_us": xch.us(),
         "roofline": {"bound": "hbm",
                      "achieved": (fwd_bytes + bwd_bytes) / (pair_ms * 1e-3) / 1e9,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -670,6 +703,8 @@ def run_model(steps, warmup, rank, world, cpu_base, B=721 * 1440):
 
     trace = bool(os.environ.get("WM_BENCH_TRACE"))
 
+    xch = Exchange(world)
+
     def step(i, timed):
         st = torch.cuda.current_stream().cuda_stream
         if trace:
@@ -687,8 +722,7 @@ def run_model(steps, warmup, rank, world, cpu_base, B=721 * 1440):
         if trace:
             torch.cuda.synchronize()
             print(f"[rank {rank}] model step {i} kernel done", file=sys.stderr, flush=True)
-        if world > 1:
-            dp.reduce_grads_(grads)          # 82 KB flat gradient buffer, one collective
+        xch.run(lambda: dp.reduce_grads_(grads), timed)   # 82 KB flat gradient buffer, one collective
         if trace:
             torch.cuda.synchronize()
             print(f"[rank {rank}] model step {i} reduced", file=sys.stderr, flush=True)
@@ -704,7 +738,7 @@ def run_model(steps, warmup, rank, world, cpu_base, B=721 * 1440):
     ach = flops * B / (kms * 1e-3) / 1e12
     res = {"value": B * world * steps / total, "unit": "grid-pts/s",
            "ms_per_step": total / steps * 1e3, "train_kernel_ms": kms,
-           "final_loss": float(loss) * world,
+           "final_loss": float(loss) * world, "exchange_us": xch.us(),
            "config": {"workload": "newConvolution.CustomModel (1->16->32->32->32 conv stack + "
                                   "192->64->6 head) fwd+bwd+Adam, 1038240 grid points per GPU per step"},
            "roofline": {"bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF,
@@ -820,6 +854,8 @@ def run_conv32(steps, warmup, rank, world, cpu_base, N=8, C=32, H=721, W=1440):
     flat = torch.zeros((C * C * 9 + C,), device="cuda")
     evs = {"fwd": [], "bwd_data": [], "bwd_wb": []}
 
+    xch = Exchange(world)
+
     def step(i, timed):
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if timed else None
         if timed:
@@ -838,7 +874,7 @@ def run_conv32(steps, warmup, rank, world, cpu_base, N=8, C=32, H=721, W=1440):
         if world > 1:
             flat[:C * C * 9] = gw.reshape(-1)
             flat[C * C * 9:] = gb
-            dp.reduce_grads_(flat)
+            xch.run(lambda: dp.reduce_grads_(flat), timed)
 
     total = timed_steps(step, steps, warmup, world)
     ms = {k: float(np.mean([a.elapsed_time(c) for a, c in v])) for k, v in evs.items()}
@@ -860,6 +896,7 @@ def run_conv32(steps, warmup, rank, world, cpu_base, N=8, C=32, H=721, W=1440):
     if cpu_base and rank == 0 and world == 1:
         base = conv_stack_cpu_library([w.cpu()], [b.cpu()], x[:1].cpu(), gy[:1].cpu(), relu=False)
     return {**({"cpu_baseline": base} if base else {}),
+            "exchange_us": xch.us(),
             "value": pts * world * steps / total, "unit": "grid-pts/s",
             "ms_per_step": total / steps * 1e3, "kernel_ms": ms,
             "config": {"workload": f"Conv2d({C}->{C}, 3x3) fwd + bwd(data, weight, bias) on "
@@ -933,11 +970,12 @@ def run_conv32x3(steps, warmup, rank, world, cpu_base, N=8, C=32, H=721, W=1440,
 
 
 # ------------------------------------------------------------------------------ Conv3D model
-def run_conv3d_model(steps, warmup, batch=16):
+def run_conv3d_model(steps, warmup, batch=16, world=1):
     """the reference's Conv3D network (convolution.py:156-180) at its own shapes,
     input (1,20,20,20), batch 16: one training step (two conv branches forward and backward, pools,
-    two dense layers, Adam) replayed from a HIP graph.  Single GPU only (the reference path has no
-    data-parallel exchange)."""
+    two dense layers, Adam) replayed from a HIP graph.  The reference path has no data-parallel
+    exchange: at N > 1 every rank trains its own replica (replicas only, no collective) and the
+    value is the sum over ranks by the slowest rank's clock."""
     from weather_model_amd.dropin._conv3d_model import Conv3DModel
     m = Conv3DModel((1, 20, 20, 20), seed=0)
     m.compile()
@@ -948,6 +986,7 @@ def run_conv3d_model(steps, warmup, batch=16):
     for _ in range(max(warmup, 3)):
         m.graphed_train_step((x1, x2, y))
     torch.cuda.synchronize()
+    barrier(world)
     t0 = time.perf_counter()
     pending = None
     for _ in range(steps):                      # as Conv3DModel.fit drives it: logs read one step late
@@ -957,16 +996,18 @@ def run_conv3d_model(steps, warmup, batch=16):
         pending = issued
     logs = pending.result()
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+    dt = max_over_ranks(time.perf_counter() - t0, world) / steps
     # 2 branches x (layer 1: 16*14^3 outputs x 32 x 343, layer 2: 16*3*3*10 x 64 x 2000) MACs forward,
     # the same again for the weight gradients, layer 2 once more for its input gradient; dense
     # layers 640x640 and 640x8000 forward + 2x backward
     conv = 2 * 2.0 * batch * (14 ** 3 * 32 * 343 + 90 * 64 * 2000)
     flops = 2 * conv + 2 * 2.0 * batch * 90 * 64 * 2000 + 3 * 2.0 * batch * (640 * 640 + 640 * 8000)
-    return {"value": batch / dt, "unit": "samples/s", "ms_per_step": dt * 1e3, "loss": logs["loss"],
+    return {"value": batch * world / dt, "unit": "samples/s", "ms_per_step": dt * 1e3,
+            "loss": logs["loss"], "exchange_us": None,
             "config": {"workload": f"Conv3D interpolation model, input (1,20,20,20), batch {batch}, "
                                    "fit step (HIP-graph replay, every step's loss and metrics "
-                                   "read back, one step late as in fit())"},
+                                   "read back, one step late as in fit())",
+                       "parallelism": f"{world} independent replica(s), no collective"},
             "roofline": {"bound": "mfma", "achieved": flops / dt / 1e12, "peak": MFMA_F32_PEAK_TF,
                          "unit": "TFLOP/s", "frac": flops / dt / 1e12 / MFMA_F32_PEAK_TF,
                          "traffic": None, "kernel": "conv3d split-K / small-volume kernels (gather-"
@@ -1164,8 +1205,8 @@ def main():
                                "rows_per_gpu": rows, "features": F,
                                "parallelism": f"dp{world} (row shards, one {F + 2}x{F + 2} f64 all-reduce)"},
                     "planted_coef_max_err": r["planted_coef_max_err"],
-                    "kernel_ms_avg": r["kernel_ms_avg"]})
-        for k in ("cpu_baseline", "cpu_baseline_port"):
+                    "kernel_ms_avg": r["kernel_ms_avg"], "exchange_us": r["exchange_us"]})
+        for k in ("cpu_baseline", "cpu_baseline_port", "solve_ms_avg"):
             if k in r:
                 out[k] = r[k]
     # the reference's OWN regression shapes, and config 2's second distribution
@@ -1191,7 +1232,7 @@ def main():
                         "ms_per_step": r["ms_per_step"], "roofline": r["roofline"],
                         "config": r["config"], "kernel_ms_avg": r["kernel_ms_avg"],
                         "planted_coef_max_err": r["planted_coef_max_err"]})
-            for k in ("cpu_baseline", "cpu_baseline_port", "solve_ms_avg"):
+            for k in ("cpu_baseline", "cpu_baseline_port", "solve_ms_avg", "exchange_us"):
                 if k in r:
                     out[k] = r[k]
         else:
@@ -1210,7 +1251,8 @@ def main():
                         "value": g64["value"], "ms_per_step": g64["ms_per_step"],
                         "roofline": g64["roofline"], "config": g64["config"],
                         "kernel_rows_per_s": g64["kernel_rows_per_s"],
-                        "planted_coef_rel_err": g64["planted_coef_rel_err"]})
+                        "planted_coef_rel_err": g64["planted_coef_rel_err"],
+                        "exchange_us": g64["exchange_us"]})
             for k in ("cpu_baseline", "cpu_baseline_port"):
                 if k in g64:
                     out[k] = g64[k]
@@ -1221,7 +1263,8 @@ def main():
         if args.workload == "conv3x3":
             out.update({"metric": "grid-pts/s conv fwd+bwd", "unit": "grid-pts/s",
                         "value": c["value"], "ms_per_step": c["ms_per_step"],
-                        "roofline": c["roofline"], "config": c["config"]})
+                        "roofline": c["roofline"], "config": c["config"],
+                        "exchange_us": c["exchange_us"]})
             for k in ("cpu_baseline", "cpu_baseline_port", "with_bwd_data"):
                 if k in c:
                     out[k] = c[k]
@@ -1232,7 +1275,8 @@ def main():
         if args.workload == "model32":
             out.update({"metric": "grid-pts/s model fwd+bwd", "unit": "grid-pts/s",
                         "value": mres["value"], "ms_per_step": mres["ms_per_step"],
-                        "roofline": mres["roofline"], "config": mres["config"]})
+                        "roofline": mres["roofline"], "config": mres["config"],
+                        "exchange_us": mres["exchange_us"]})
             for k in ("cpu_baseline", "cpu_baseline_port"):
                 if k in mres:
                     out[k] = mres[k]
@@ -1244,7 +1288,7 @@ def main():
             out.update({"metric": "grid-pts/s conv32 fwd+bwd", "unit": "grid-pts/s",
                         "value": cres["value"], "ms_per_step": cres["ms_per_step"],
                         "roofline": cres["roofline"], "config": cres["config"],
-                        "kernel_ms": cres["kernel_ms"]})
+                        "kernel_ms": cres["kernel_ms"], "exchange_us": cres["exchange_us"]})
             if cres.get("cpu_baseline"):
                 out["cpu_baseline"] = cres["cpu_baseline"]
         else:
@@ -1274,8 +1318,8 @@ def main():
                 out["cpu_baseline"] = fres["cpu_baseline"]
         else:
             out.setdefault("also", {})["fields"] = fres
-    if args.workload in ("all", "conv3d_model") and world == 1:
-        c3 = run_conv3d_model(args.steps, args.warmup)
+    if args.workload in ("all", "conv3d_model"):
+        c3 = run_conv3d_model(args.steps, args.warmup, world=world)
         if args.workload == "conv3d_model":
             out.update({"metric": "samples/s Conv3D model fit step", "unit": "samples/s",
                         "value": c3["value"], "ms_per_step": c3["ms_per_step"],

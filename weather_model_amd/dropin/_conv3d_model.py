@@ -13,8 +13,10 @@ Convolutions, pools and their gradients are the hand-written kernels (``ops.conv
 ``ops.maxpool3d``), loss + metrics + loss gradient are one hand-written pass (``ops.mse_metrics``);
 the two Dense layers are the skinny MFMA products of ``dense.hip`` (``ops.dense``: bias + ReLU in the
 forward store, dense1's ReLU backward in the output layer's input-gradient store; widths that are
-not multiples of 4 floats go to ``torch.nn.functional.linear``) and Adam is ``torch.optim.Adam``
-with Keras' epsilon.  No CPU path.
+not multiples of 4 floats are refused at construction -- the reference's 640 and 8000 are) and Adam
+is ``torch.optim.Adam`` with Keras' epsilon (its fused multi-tensor kernel moves the 5.8 M
+parameters' 162 MB in 44 us, i.e. at the memory rate: a hand-written one would not be faster).
+No CPU path.
 
 Parity: unpinned against the reference's own run (tensorflow/keras absent here); the operators are
 pinned against the float64 oracle and torch-CPU vectors, the assembled network against a plain
@@ -26,7 +28,6 @@ from math import prod
 
 import numpy as np
 import torch
-import torch.nn.functional as F
 
 from weather_model_amd import ops
 from ._keras_like import History, _MSLE_EPS, _batches
@@ -85,6 +86,12 @@ class Conv3DModel:
             flat = prod(cur[1:])
         self.flat = 2 * flat
         self.out_dim = prod(self.input_shape)
+        if not (ops.dense_supported(self.flat, self.flat) and
+                ops.dense_supported(self.flat, self.out_dim)):
+            raise ValueError(
+                f"input {self.input_shape} gives Dense widths {self.flat} -> {self.flat} -> "
+                f"{self.out_dim}; wm_dense_*_f32 takes multiples of 4 floats (16-byte rows) and "
+                "this model has no library fallback")
         self.params["dense1/kernel"] = _glorot((self.flat, self.flat), self.flat, self.flat, gen,
                                                self.device)
         self.params["dense1/bias"] = torch.zeros((self.flat,), device=self.device,
@@ -114,14 +121,11 @@ class Conv3DModel:
     def forward(self, x1, x2):
         h = torch.cat((self._branch(x1, "1"), self._branch(x2, "2")), dim=1)
         p = self.params
-        if ops.dense_supported(self.flat, self.flat) and ops.dense_supported(self.flat, self.out_dim):
-            # hand-written skinny products; dense1's ReLU backward is applied in the output
-            # layer's input-gradient store
-            h = ops.dense(h, p["dense1/kernel"], p["dense1/bias"], relu=True, relu_bwd_fused=True)
-            return ops.dense(h, p["output/kernel"], p["output/bias"], relu_input=True)
-        # widths that are not multiples of 4 floats: plain library GEMMs
-        h = F.relu(F.linear(h, p["dense1/kernel"], p["dense1/bias"]))
-        return F.linear(h, p["output/kernel"], p["output/bias"])
+        # hand-written skinny products; dense1's ReLU backward is applied in the output layer's
+        # input-gradient store.  (Widths that are not multiples of 4 floats are refused in
+        # __init__: there is no library fallback behind this path.)
+        h = ops.dense(h, p["dense1/kernel"], p["dense1/bias"], relu=True, relu_bwd_fused=True)
+        return ops.dense(h, p["output/kernel"], p["output/bias"], relu_input=True)
 
     def _to_dev(self, a):
         t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a, np.float32))
