@@ -4,7 +4,7 @@
 set -u
 tag=${1:-run}
 ROOT=$(pwd)
-timeout -k 10 400 python3 -u bench.py --workload all > gpurun_out/bench_$tag.log 2>&1 || { echo "bench failed"; tail -5 gpurun_out/bench_$tag.log; exit 1; }
+timeout -k 10 700 python3 -u bench.py --workload all > gpurun_out/bench_$tag.log 2>&1 || { echo "bench failed"; tail -5 gpurun_out/bench_$tag.log; exit 1; }
 tail -1 gpurun_out/bench_$tag.log > gpurun_out/bench_$tag.json
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_$tag -- \
