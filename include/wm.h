@@ -81,6 +81,31 @@ int wm_conv2d_bwd_wb_f32(const float *x, const float *gy, float *gw, float *gb,
                          int N, int Cin, int H, int W, int Cout, int kH, int kW,
                          void *stream);
 
+/* Deferred finalize of the same gradient legs (newConvolution.py:184-186: loss.backward() followed at
+ * once by optimizer.step()): wm_conv2d_bwd_wb_f32 = a partial-sum pass + a small dependent launch that
+ * adds the partials in a fixed order.  These three entry points split the two so that the consumer
+ * which runs next anyway does the fixed-order sum:
+ *   wm_conv2d_bwd_wb_partials_f32   the partial-sum pass alone; `workspace` (sized as above) then
+ *                                   holds float64 partials, layout[0] of them per entry, entry-major
+ *                                   ([nw+Cout][layout[0]]) when layout[1] == 1, else part-major.
+ *                                   Shapes that take the MFMA weight-gradient kernels (both channel
+ *                                   counts >= 16) are WM_ERR_UNSUPPORTED: call wm_conv2d_bwd_wb_f32.
+ *   wm_partials_finish_f32          the fixed-order sum -> gw (nw floats), gb (nb floats or NULL).
+ *   wm_adam_step_partials_f32       the sum fused into the Adam update of the layer's flat parameter
+ *                                   vector [w | b] (count = nw + nb; torch.optim.Adam defaults as in
+ *                                   wm_adam_step_f32, newConvolution.py:225); grads_out (count floats
+ *                                   or NULL) receives the float32 gradient.
+ * partials + finish, and partials + adam_step_partials, give bit for bit what wm_conv2d_bwd_wb_f32
+ * (followed by wm_adam_step_f32) gives. */
+int wm_conv2d_bwd_wb_partials_f32(const float *x, const float *gy, void *workspace,
+                                  size_t workspace_bytes, int N, int Cin, int H, int W, int Cout,
+                                  int kH, int kW, int *layout, void *stream);
+int wm_partials_finish_f32(const void *partials, int nparts, int entry_major, int nw, int nb,
+                           float *gw, float *gb, void *stream);
+int wm_adam_step_partials_f32(float *params, const void *partials, int nparts, int entry_major,
+                              float *m, float *v, int count, float *grads_out, int step, double lr,
+                              double beta1, double beta2, double eps, float grad_scale, void *stream);
+
 /* No counterpart in the reference.  The same gradients as wm_conv2d_bwd_wb_f32 for callers that
  * cannot allocate device memory (code under HIP graph capture, tight serving loops, harnesses that
  * forbid hipMalloc): the float64 partial sums live in a static device array of

@@ -211,6 +211,53 @@ def test_conv_bwd_wb_is_bitwise_reproducible():
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
 
 
+@pytest.mark.parametrize("shape", [
+    (4, 1, 200, 300, 1, 3, 3),    # flat stencil kernel: entry-major partials
+    (64, 1, 721, 1440, 1, 3, 3),  # BASELINE configs[2] at full size
+    (5, 1, 40, 66, 1, 3, 3),      # strip stencil kernel (W % 4 != 0): part-major partials
+    (1, 1, 4, 4100, 1, 3, 3),     # too wide for the flat kernels
+    (2, 3, 8, 9, 2, 2, 3),        # generic kernel
+    (3, 16, 12, 20, 1, 3, 1),     # the reference's conv2 orientation transposed: Cout = 1
+])
+def test_conv_bwd_wb_deferred_finalize_is_bit_identical(shape):
+    """wm_conv2d_bwd_wb_partials_f32 + wm_partials_finish_f32 == wm_conv2d_bwd_wb_f32, and
+    + wm_adam_step_partials_f32 == wm_conv2d_bwd_wb_f32 + wm_adam_step_f32, bit for bit, over
+    three chained steps (newConvolution.py:184-186)."""
+    from weather_model_amd import ops, synth
+    N, Cin, H, W, Cout, kH, kW = shape
+    wshape = (Cout, Cin, kH, kW)
+    x = _dev(synth.uniform(80, (N, Cin, H, W)))
+    gy = _dev(synth.uniform(81, (N, Cout, H - kH + 1, W - kW + 1), -1, 1))
+    gw, gb = ops.conv2d_backward_wb(x, gy, wshape)
+    part = ops.conv2d_backward_wb_partials(x, gy, wshape)
+    gw2, gb2 = part.finish()
+    assert torch.equal(gw, gw2) and torch.equal(gb, gb2)
+    gw3, none = part.finish(need_bias=False)
+    assert none is None and torch.equal(gw, gw3)
+    nent = gw.numel() + gb.numel()
+    p0 = _dev(synth.uniform(82, (nent,), -0.5, 0.5))
+    pa, ma, va = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+    pb, mb, vb = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+    gout = torch.empty_like(p0)
+    for step in (1, 2, 3):
+        xs = x * float(step)
+        g = torch.cat([t.reshape(-1) for t in ops.conv2d_backward_wb(xs, gy, wshape)])
+        ops.adam_step(pa, g, ma, va, step, lr=1e-2, grad_scale=0.5)
+        part = ops.conv2d_backward_wb_partials(xs, gy, wshape, ws=part.ws)
+        ops.adam_step_partials(pb, part, mb, vb, step, lr=1e-2, grad_scale=0.5, grads_out=gout)
+        assert torch.equal(g, gout)
+        assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
+    assert not torch.equal(pa, p0)
+
+
+def test_conv_bwd_wb_deferred_rejects_mfma_shapes():
+    from weather_model_amd import ops, _lib
+    x = torch.zeros(2, 16, 200, 400, device="cuda")
+    gy = torch.zeros(2, 24, 198, 398, device="cuda")
+    with pytest.raises(_lib.WmError, match="not deferrable"):
+        ops.conv2d_backward_wb_partials(x, gy, (24, 16, 3, 3))
+
+
 def test_conv_error_behaviour():
     from weather_model_amd import ops, _lib
     x = torch.zeros(1, 2, 5, 5, device="cuda")

@@ -23,6 +23,10 @@ SIGNATURES = {
     "wm_conv3d_bwd_data_relu_f32": (c_int, [vp, vp, vp, vp] + [c_int] * 9 + [vp]),
     "wm_conv2d_bwd_wb_workspace_bytes": (c_sz, [c_int] * 7),
     "wm_conv2d_bwd_wb_f32": (c_int, [vp, vp, vp, vp, vp, c_sz] + [c_int] * 7 + [vp]),
+    "wm_conv2d_bwd_wb_partials_f32": (c_int, [vp, vp, vp, c_sz] + [c_int] * 7 + [vp, vp]),
+    "wm_partials_finish_f32": (c_int, [vp, c_int, c_int, c_int, c_int, vp, vp, vp]),
+    "wm_adam_step_partials_f32": (c_int, [vp, vp, c_int, c_int, vp, vp, c_int, vp, c_int, c_f64,
+                                          c_f64, c_f64, c_f64, c_f32, vp]),
     "wm_conv2d_bwd_wb_noalloc_max_bytes": (c_sz, []),
     "wm_conv2d_bwd_wb_noalloc_f32": (c_int, [vp, vp, vp, vp] + [c_int] * 7 + [vp]),
     "wm_conv3d_fwd_f32": (c_int, [vp, vp, vp, vp] + [c_int] * 9 + [c_int, vp]),

@@ -71,3 +71,20 @@ __device__ __forceinline__ double wave_sum(double v)
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+
+// One Adam update (torch.optim.Adam single-tensor order, see adam_kernel in model.hip); shared by
+// wm_adam_step_f32 and the deferred-finalize form wm_adam_step_partials_f32 so the two agree bit
+// for bit.
+struct AdamScalars {
+    float one_minus_b1, b2, one_minus_b2, eps, step_size, bc2_sqrt, gscale;
+};
+__device__ __forceinline__ void adam_update(float &p, float &m, float &v, float g, const AdamScalars &a)
+{
+    const float gv = g * a.gscale;
+    const float mn = m + a.one_minus_b1 * (gv - m);
+    const float vn = a.b2 * v + (a.one_minus_b2 * gv) * gv;
+    m = mn;
+    v = vn;
+    const float denom = sqrtf(vn) / a.bc2_sqrt + a.eps;
+    p = p - a.step_size * (mn / denom);
+}

@@ -840,15 +840,21 @@ __global__ __launch_bounds__(1024) void conv_bwd_data_c1f_kernel(
 // ------------------------------------------------------------------------------------------
 // fixed-order float64 reduction of per-block partials: one wave per output entry.
 // partial is [nparts][nent]; out_w gets entries [0, nw), out_b gets [nw, nent).
+__device__ __forceinline__ double sum_part_major(const double *__restrict__ partial, int nparts,
+                                                 int nent, int e)
+{
+    double s = 0.0;
+    for (int p = threadIdx.x; p < nparts; p += 64) s += partial[(size_t)p * nent + e];
+    return wave_sum(s);
+}
+
 __global__ __launch_bounds__(64) void reduce_partials_kernel(const double *__restrict__ partial,
                                                             int nparts, int nent, int nw,
                                                             float *__restrict__ out_w,
                                                             float *__restrict__ out_b)
 {
     const int e = blockIdx.x;
-    double s = 0.0;
-    for (int p = threadIdx.x; p < nparts; p += 64) s += partial[(size_t)p * nent + e];
-    s = wave_sum(s);
+    const double s = sum_part_major(partial, nparts, nent, e);
     if (threadIdx.x == 0) {
         if (e < nw) out_w[e] = (float)s;
         else if (out_b) out_b[e - nw] = (float)s;
@@ -857,23 +863,53 @@ __global__ __launch_bounds__(64) void reduce_partials_kernel(const double *__res
 
 // The same for entry-major partials [nent][nparts] (the flat stencil kernel): one 256-thread
 // workgroup per entry, coalesced 8-byte loads, fixed order (thread t adds partials t, t+256, ...;
-// butterfly across the wave; the four wave sums in wave order).
-__global__ __launch_bounds__(256) void reduce_partials_wide_kernel(
-    const double *__restrict__ partial, int nparts, int nw, float *__restrict__ out_w,
-    float *__restrict__ out_b)
+// butterfly across the wave; the four wave sums in wave order).  The total is valid in thread 0.
+__device__ __forceinline__ double sum_entry_major(const double *__restrict__ partial, int nparts,
+                                                  int e, double (&wsum)[4])
 {
-    __shared__ double wsum[4];
-    const int e = blockIdx.x;
     const double *__restrict__ src = partial + (size_t)e * nparts;
     double s = 0.0;
     for (int p = threadIdx.x; p < nparts; p += 256) s += src[p];
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
     __syncthreads();
+    return ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
+}
+
+__global__ __launch_bounds__(256) void reduce_partials_wide_kernel(
+    const double *__restrict__ partial, int nparts, int nw, float *__restrict__ out_w,
+    float *__restrict__ out_b)
+{
+    __shared__ double wsum[4];
+    const int e = blockIdx.x;
+    const double t = sum_entry_major(partial, nparts, e, wsum);
     if (threadIdx.x == 0) {
-        const double t = ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
         if (e < nw) out_w[e] = (float)t;
         else if (out_b) out_b[e - nw] = (float)t;
+    }
+}
+
+// Deferred finalize (wm_adam_step_partials_f32): the consumer of the gradient does the fixed-order
+// sum itself -- one workgroup per parameter sums that entry's partials exactly as the two kernels
+// above do, rounds to float32 once, and applies the Adam update.  One launch instead of
+// finalize + Adam, bit-identical parameters.
+template <bool ENTRY_MAJOR>
+__global__ __launch_bounds__(ENTRY_MAJOR ? 256 : 64) void adam_partials_kernel(
+    float *__restrict__ prm, const double *__restrict__ partial, int nparts, int nent,
+    float *__restrict__ m, float *__restrict__ v, float *__restrict__ grads_out, AdamScalars a)
+{
+    __shared__ double wsum[4];
+    const int e = blockIdx.x;
+    const double t = ENTRY_MAJOR ? sum_entry_major(partial, nparts, e, wsum)
+                                 : sum_part_major(partial, nparts, nent, e);
+    if (threadIdx.x == 0) {
+        const float g = (float)t;
+        if (grads_out) grads_out[e] = g;
+        float pv = prm[e], mv = m[e], vv = v[e];
+        adam_update(pv, mv, vv, g, a);
+        m[e] = mv;
+        v[e] = vv;
+        prm[e] = pv;
     }
 }
 
@@ -1374,24 +1410,18 @@ extern "C" size_t wm_conv2d_bwd_wb_workspace_bytes(int N, int Cin, int H, int W,
     return wm_align_up((size_t)splits * nent * sizeof(double), 256);
 }
 
-extern "C" int wm_conv2d_bwd_wb_f32(const float *x, const float *gy, float *gw, float *gb,
-                                    void *workspace, size_t workspace_bytes, int N, int Cin, int H,
-                                    int W, int Cout, int kH, int kW, void *stream)
+// The partial-sum pass of the weight/bias gradient for the shapes that do not go to the MFMA
+// kernels: float64 partials in `partial`, nparts of them per entry, entry-major ([nent][nparts],
+// the flat stencil kernel) or part-major ([nparts][nent]).
+static int bwd_wb_partials_launch(const float *x, const float *gy, double *partial,
+                                  size_t workspace_bytes, int N, int Cin, int H, int W, int Cout,
+                                  int kH, int kW, hipStream_t st, int *nparts_out,
+                                  int *entry_major_out)
 {
-    WM_REQUIRE(x && gy && gw, WM_ERR_INVALID, "wm_conv2d_bwd_wb_f32: null pointer");
-    if (int rc = check_dims(N, Cin, H, W, Cout, kH, kW)) return rc;
-    const size_t need = wm_conv2d_bwd_wb_workspace_bytes(N, Cin, H, W, Cout, kH, kW);
-    WM_REQUIRE(workspace && workspace_bytes >= need, WM_ERR_WORKSPACE,
-               "wm_conv2d_bwd_wb_f32: workspace of %zu bytes needed, %zu given", need,
-               workspace_bytes);
-    hipStream_t st = (hipStream_t)stream;
     const int OH = H - kH + 1, OW = W - kW + 1;
-    if (mfma_shape(N, Cin, H, W, Cout, kH, kW))
-        return wm_conv3d_bwd_wb_f32(x, gy, gw, gb, workspace, workspace_bytes, N, Cin, 1, H, W,
-                                    Cout, 1, kH, kW, stream);
     const int nw = Cout * Cin * kH * kW, nent = nw + Cout;
-    double *partial = (double *)workspace;
     int nparts = 0;
+    *entry_major_out = 0;
     if (stencil_shape(Cin, Cout, kH, kW, OW, (long long)N * H)) {
 #define BWDF(KH_, KW_)                                                                          \
     FlatPlan fp;                                                                                \
@@ -1411,9 +1441,8 @@ extern "C" int wm_conv2d_bwd_wb_f32(const float *x, const float *gy, float *gw, 
                            dim3(fp.waves * 64), 0, st, x, gy, partial, H, W, OH, OW,            \
                            fp.rows_base, fp.rows_rem, (unsigned)fp.segs);                       \
         WM_LAUNCH_CHECK("conv_bwd_wb_c1f_kernel");                                              \
-        hipLaunchKernelGGL(reduce_partials_wide_kernel, dim3(nent), dim3(256), 0, st, partial,  \
-                           fp.segs, nw, gw, gb);                                                \
-        WM_LAUNCH_CHECK("reduce_partials_wide_kernel");                                         \
+        *nparts_out = (int)fp.segs;                                                             \
+        *entry_major_out = 1;                                                                   \
         return WM_OK;                                                                           \
     }
         WM_STENCIL_DISPATCH(BWDF)
@@ -1439,9 +1468,99 @@ extern "C" int wm_conv2d_bwd_wb_f32(const float *x, const float *gy, float *gw, 
         WM_LAUNCH_CHECK("conv_bwd_wb_generic_kernel");
         nparts = splits;
     }
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(nent), dim3(64), 0, st, partial, nparts, nent,
-                       nw, gw, gb);
-    WM_LAUNCH_CHECK("reduce_partials_kernel");
+    *nparts_out = nparts;
+    return WM_OK;
+}
+
+static int partials_finish_launch(const double *partial, int nparts, int entry_major, int nw,
+                                  int nb, float *gw, float *gb, hipStream_t st)
+{
+    const int nent = nw + nb;
+    if (entry_major) {
+        hipLaunchKernelGGL(reduce_partials_wide_kernel, dim3(nent), dim3(256), 0, st, partial,
+                           nparts, nw, gw, gb);
+        WM_LAUNCH_CHECK("reduce_partials_wide_kernel");
+    } else {
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(nent), dim3(64), 0, st, partial, nparts,
+                           nent, nw, gw, gb);
+        WM_LAUNCH_CHECK("reduce_partials_kernel");
+    }
+    return WM_OK;
+}
+
+extern "C" int wm_conv2d_bwd_wb_f32(const float *x, const float *gy, float *gw, float *gb,
+                                    void *workspace, size_t workspace_bytes, int N, int Cin, int H,
+                                    int W, int Cout, int kH, int kW, void *stream)
+{
+    WM_REQUIRE(x && gy && gw, WM_ERR_INVALID, "wm_conv2d_bwd_wb_f32: null pointer");
+    if (int rc = check_dims(N, Cin, H, W, Cout, kH, kW)) return rc;
+    const size_t need = wm_conv2d_bwd_wb_workspace_bytes(N, Cin, H, W, Cout, kH, kW);
+    WM_REQUIRE(workspace && workspace_bytes >= need, WM_ERR_WORKSPACE,
+               "wm_conv2d_bwd_wb_f32: workspace of %zu bytes needed, %zu given", need,
+               workspace_bytes);
+    hipStream_t st = (hipStream_t)stream;
+    if (mfma_shape(N, Cin, H, W, Cout, kH, kW))
+        return wm_conv3d_bwd_wb_f32(x, gy, gw, gb, workspace, workspace_bytes, N, Cin, 1, H, W,
+                                    Cout, 1, kH, kW, stream);
+    int nparts = 0, entry_major = 0;
+    if (int rc = bwd_wb_partials_launch(x, gy, (double *)workspace, workspace_bytes, N, Cin, H, W,
+                                        Cout, kH, kW, st, &nparts, &entry_major))
+        return rc;
+    return partials_finish_launch((const double *)workspace, nparts, entry_major,
+                                  Cout * Cin * kH * kW, Cout, gw, gb, st);
+}
+
+// Deferred finalize: the partial-sum pass alone.  layout[0] = partials per entry, layout[1] = 1 if
+// the workspace holds them entry-major.  wm_partials_finish_f32 or wm_adam_step_partials_f32
+// consume them; the sums are the ones wm_conv2d_bwd_wb_f32 forms, in the same order.
+extern "C" int wm_conv2d_bwd_wb_partials_f32(const float *x, const float *gy, void *workspace,
+                                             size_t workspace_bytes, int N, int Cin, int H, int W,
+                                             int Cout, int kH, int kW, int *layout, void *stream)
+{
+    WM_REQUIRE(x && gy && layout, WM_ERR_INVALID, "wm_conv2d_bwd_wb_partials_f32: null pointer");
+    if (int rc = check_dims(N, Cin, H, W, Cout, kH, kW)) return rc;
+    WM_REQUIRE(!mfma_shape(N, Cin, H, W, Cout, kH, kW), WM_ERR_UNSUPPORTED,
+               "wm_conv2d_bwd_wb_partials_f32: this shape takes the MFMA weight-gradient kernels, "
+               "whose slab reduction is not deferrable -- use wm_conv2d_bwd_wb_f32");
+    const size_t need = wm_conv2d_bwd_wb_workspace_bytes(N, Cin, H, W, Cout, kH, kW);
+    WM_REQUIRE(workspace && workspace_bytes >= need, WM_ERR_WORKSPACE,
+               "wm_conv2d_bwd_wb_partials_f32: workspace of %zu bytes needed, %zu given", need,
+               workspace_bytes);
+    return bwd_wb_partials_launch(x, gy, (double *)workspace, workspace_bytes, N, Cin, H, W, Cout,
+                                  kH, kW, (hipStream_t)stream, &layout[0], &layout[1]);
+}
+
+extern "C" int wm_partials_finish_f32(const void *partials, int nparts, int entry_major, int nw,
+                                      int nb, float *gw, float *gb, void *stream)
+{
+    WM_REQUIRE(partials && gw && nparts > 0 && nw > 0 && nb >= 0, WM_ERR_INVALID,
+               "wm_partials_finish_f32: bad arguments");
+    return partials_finish_launch((const double *)partials, nparts, entry_major, nw, nb, gw, gb,
+                                  (hipStream_t)stream);
+}
+
+extern "C" int wm_adam_step_partials_f32(float *params, const void *partials, int nparts,
+                                         int entry_major, float *m, float *v, int count,
+                                         float *grads_out, int step, double lr, double beta1,
+                                         double beta2, double eps, float grad_scale, void *stream)
+{
+    WM_REQUIRE(params && partials && m && v, WM_ERR_INVALID,
+               "wm_adam_step_partials_f32: null pointer");
+    WM_REQUIRE(count > 0 && nparts > 0 && step >= 1, WM_ERR_INVALID,
+               "wm_adam_step_partials_f32: bad count/nparts/step");
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
+    const AdamScalars a{(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
+                        (float)(lr / bc1), (float)sqrt(bc2), grad_scale};
+    if (entry_major)
+        hipLaunchKernelGGL(adam_partials_kernel<true>, dim3(count), dim3(256), 0,
+                           (hipStream_t)stream, params, (const double *)partials, nparts, count, m,
+                           v, grads_out, a);
+    else
+        hipLaunchKernelGGL(adam_partials_kernel<false>, dim3(count), dim3(64), 0,
+                           (hipStream_t)stream, params, (const double *)partials, nparts, count, m,
+                           v, grads_out, a);
+    WM_LAUNCH_CHECK("adam_partials_kernel");
     return WM_OK;
 }
 

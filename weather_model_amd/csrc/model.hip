@@ -735,20 +735,15 @@ __global__ __launch_bounds__(256) void model_grad_finalize_kernel(const double *
 // every scalar is computed in double on the host and rounded to float once, as torch does.
 __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ gr,
                                                    float *__restrict__ m, float *__restrict__ v,
-                                                   long long count, float one_minus_b1, float b2,
-                                                   float one_minus_b2, float eps, float step_size,
-                                                   float bc2_sqrt, float gscale)
+                                                   long long count, AdamScalars a)
 {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= count) return;
-    const float gv = gr[idx] * gscale;
-    const float mo = m[idx];
-    const float mn = mo + one_minus_b1 * (gv - mo);
-    const float vn = b2 * v[idx] + (one_minus_b2 * gv) * gv;
-    m[idx] = mn;
-    v[idx] = vn;
-    const float denom = sqrtf(vn) / bc2_sqrt + eps;
-    p[idx] = p[idx] - step_size * (mn / denom);
+    float pv = p[idx], mv = m[idx], vv = v[idx];
+    adam_update(pv, mv, vv, gr[idx], a);
+    m[idx] = mv;
+    v[idx] = vv;
+    p[idx] = pv;
 }
 
 int model_grid(long long B)
@@ -925,10 +920,10 @@ extern "C" int wm_adam_step_f32(float *params, const float *grads, float *m, flo
     // 1 - 0.999f is already off by 1.3e-5 relative, a systematic error in every early update
     const double bc1 = 1.0 - pow(beta1, (double)step);
     const double bc2 = 1.0 - pow(beta2, (double)step);
+    const AdamScalars a{(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
+                        (float)(lr / bc1), (float)sqrt(bc2), grad_scale};
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, params, grads, m, v, (long long)count,
-                       (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
-                       (float)(lr / bc1), (float)sqrt(bc2), grad_scale);
+                       (hipStream_t)stream, params, grads, m, v, (long long)count, a);
     WM_LAUNCH_CHECK("adam_kernel");
     return WM_OK;
 }

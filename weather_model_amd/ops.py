@@ -12,6 +12,7 @@ raises otherwise -- there is no CPU path in the product.
 from __future__ import annotations
 
 import ctypes
+import math
 
 import torch
 
@@ -139,6 +140,75 @@ def conv2d_backward_wb(x, gy, w_shape, need_bias=True, ws=None, out_w=None, out_
             x.data_ptr(), gy.data_ptr(), gw.data_ptr(), 0 if gb is None else gb.data_ptr(),
             ws.data_ptr(), ws.numel(), N, Cin, H, W, Cout, kH, kW, _stream()))
     return gw, gb
+
+
+class GradPartials:
+    """The float64 partial sums a deferred weight/bias gradient leaves in its workspace
+    (wm_conv2d_bwd_wb_partials_f32): consumed by ``finish()`` or ``adam_step_partials``."""
+
+    def __init__(self, ws, nparts, entry_major, w_shape):
+        self.ws, self.nparts, self.entry_major = ws, int(nparts), int(entry_major)
+        self.w_shape = tuple(int(v) for v in w_shape)
+        self.nw = math.prod(self.w_shape)
+        self.nb = self.w_shape[0]
+
+    def finish(self, need_bias=True, out_w=None, out_b=None):
+        """The fixed-order sum: bit for bit the (gw, gb) of ``conv2d_backward_wb``."""
+        dev = self.ws.device
+        with torch.cuda.device(dev):
+            gw = _out_like(out_w, self.w_shape, dev, "out_w")
+            gb = _out_like(out_b, (self.nb,), dev, "out_b") if need_bias else None
+            _lib.check(_lib.lib().wm_partials_finish_f32(
+                self.ws.data_ptr(), self.nparts, self.entry_major, self.nw, self.nb, gw.data_ptr(),
+                0 if gb is None else gb.data_ptr(), _stream()))
+        return gw, gb
+
+
+def conv2d_backward_wb_partials(x, gy, w_shape, ws=None):
+    """Deferred-finalize form of ``conv2d_backward_wb`` (newConvolution.py:184-186): the partial-sum
+    pass only; the consumer that runs next (``adam_step_partials`` / ``GradPartials.finish``) adds
+    the partials in the fixed order.  Shapes on the MFMA kernels raise WmError (unsupported)."""
+    x, gy = _req(x, "input"), _req(gy, "grad_output")
+    N, Cin, H, W = x.shape
+    Cout, _, kH, kW = w_shape
+    L = _lib.lib()
+    with torch.cuda.device(x.device):
+        nbytes = L.wm_conv2d_bwd_wb_workspace_bytes(N, Cin, H, W, Cout, kH, kW)
+        if ws is None:
+            ws = torch.empty((max(nbytes, 8),), device=x.device, dtype=torch.uint8)
+        elif ws.numel() < nbytes or not ws.is_cuda or ws.dtype != torch.uint8:
+            raise ValueError(f"ws must be a CUDA uint8 tensor of at least {nbytes} bytes")
+        layout = (ctypes.c_int * 2)()
+        _lib.check(L.wm_conv2d_bwd_wb_partials_f32(
+            x.data_ptr(), gy.data_ptr(), ws.data_ptr(), ws.numel(), N, Cin, H, W, Cout, kH, kW,
+            ctypes.cast(layout, ctypes.c_void_p), _stream()))
+    return GradPartials(ws, layout[0], layout[1], w_shape)
+
+
+def adam_step_partials(params, partials, m, v, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8,
+                       grad_scale=1.0, grads_out=None):
+    """Adam on the flat [w | b] parameter vector of one layer, with the fixed-order sum of the
+    deferred gradient's partials fused in (one launch instead of finalize + Adam; same bits)."""
+    if not isinstance(partials, GradPartials):
+        raise TypeError("adam_step_partials: partials must come from conv2d_backward_wb_partials")
+    count = partials.nw + partials.nb
+    for name, t in (("params", params), ("m", m), ("v", v), ("grads_out", grads_out)):
+        if t is None and name == "grads_out":
+            continue
+        if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.float32 or \
+                not t.is_contiguous():
+            raise TypeError(f"adam_step_partials: {name} must be a contiguous float32 CUDA tensor")
+        if t.numel() != count or t.device != partials.ws.device:
+            raise ValueError(f"adam_step_partials: {name} has {t.numel()} elements on {t.device}, "
+                             f"the layer has {count} parameters on {partials.ws.device}")
+    if int(step) < 1:
+        raise ValueError("adam_step_partials: step counts from 1")
+    with torch.cuda.device(params.device):
+        _lib.check(_lib.lib().wm_adam_step_partials_f32(
+            params.data_ptr(), partials.ws.data_ptr(), partials.nparts, partials.entry_major,
+            m.data_ptr(), v.data_ptr(), count, 0 if grads_out is None else grads_out.data_ptr(),
+            int(step), float(lr), float(beta1), float(beta2), float(eps), float(grad_scale),
+            _stream()))
 
 
 class Conv2dFunction(torch.autograd.Function):
