@@ -1131,7 +1131,7 @@ def run_fields(steps, warmup, rank, world, cpu_base):
             if t:
                 e[1].record()
                 ev.append(e)
-        total = timed_steps(step, steps, warmup, world, tag="conv3d_model")
+        total = timed_steps(step, steps, warmup, world, tag="fields")
         return total / steps, float(np.mean([a.elapsed_time(c) for a, c in ev])) * 1e-3
 
     t_stat, k_stat = timed(lambda i: ops.field_stats(fields[i % nset], stat))
@@ -1139,7 +1139,7 @@ def run_fields(steps, warmup, rank, world, cpu_base):
                                                       out=outs[i % nset]))
     t_gath, k_gath = timed(lambda i: ops.gather_triplets(vol, (T - 6, Z, Y, X), first=0, count=B))
     res = {
-        "prewarm_steps": PREWARM_LOG.get("conv3d_model"),
+        "prewarm_steps": PREWARM_LOG.get("fields"),
         "unit": "elements/s",
         "config": {"workload": "field kernels: stats + normalise over 64x721x1440 fp32, triplet "
                                "gather of one 721x1440 slice (6 variables), regression rows from a "

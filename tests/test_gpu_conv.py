@@ -144,6 +144,11 @@ def test_conv32_full_size_adjoint_identities():
     (2, 16, 200, 400, 24, 3, 3),  # multi-channel, > 131072 outputs: wide MFMA kernel, ragged Cout
     (1, 20, 140, 1000, 40, 2, 3), # wide MFMA kernel, ragged Cin, three channel tiles
     (2, 16, 600, 900, 24, 3, 3),  # > 2^20 outputs: the persistent wide weight-gradient kernel
+    # the LDS-ring kernel (conv_ring.hip): ragged channel counts on both sides, kernels up to 5 x 4,
+    # the reference's (3, 1) orientation, one 64-column stripe exactly, three channel tiles, one tile
+    (4, 8, 140, 330, 24, 3, 3), (4, 6, 120, 300, 20, 5, 4), (6, 16, 200, 128, 32, 3, 1),
+    (20, 32, 130, 66, 32, 3, 3), (5, 12, 100, 300, 48, 3, 3), (5, 20, 100, 300, 10, 2, 2),
+    (3, 33, 150, 200, 35, 1, 2),
     (1, 1, 7, 7, 1, 7, 7),        # generic path, 1x1 output
     (2, 3, 8, 9, 2, 2, 3),        # generic path, odd everything
 ])
@@ -175,6 +180,35 @@ def test_conv_ragged_shapes_vs_oracle(shape):
     mag_w, mag_b = ocpu.conv2d_bwd_wb(np.abs(x), np.abs(gy), w.shape)
     assert (np.abs(gw2.cpu().numpy() - ogw2) <= TOL * mag_w).all()
     assert (np.abs(gb2.cpu().numpy() - ogb2) <= TOL * mag_b).all()
+
+
+@pytest.mark.parametrize("shape", [
+    (4, 32, 140, 330, 32, 3, 3),   # the LDS-ring kernel (conv_ring.hip): BASELINE configs[3]'s channel counts
+    (5, 20, 100, 300, 14, 3, 3),   # ring, ragged on both sides (input gradient: 14 -> 20 channels)
+    (3, 16, 150, 200, 35, 3, 3),   # row kernels (three channel tiles on the forward side)
+])
+def test_conv_fused_relu_paths_vs_oracle(shape):
+    """Forward with the ReLU fused into the store (newConvolution.py:150-159) and the input gradient
+    with the ReLU backward of the layer below fused in (loss.backward(), :184), on shapes large
+    enough for the ring / row kernels."""
+    from weather_model_amd import ops, synth
+    from oracle import cpu as ocpu
+    N, Cin, H, W, Cout, kH, kW = shape
+    x = synth.uniform(90, (N, Cin, H, W), -1, 1)
+    w = synth.uniform(91, (Cout, Cin, kH, kW), -1, 1)
+    b = synth.uniform(92, (Cout,), -1, 1)
+    gy = synth.uniform(93, (N, Cout, H - kH + 1, W - kW + 1), -1, 1)
+    below = synth.uniform(94, (N, Cin, H, W), -1, 1)          # the layer below's post-ReLU output
+    below = np.maximum(below, 0.0).astype(np.float32)
+    y = ops.conv2d_forward(_dev(x), _dev(w), _dev(b), relu=True).cpu().numpy()
+    ref = ocpu.conv2d_fwd(x, w, b)
+    assert relinf(y, np.maximum(ref, 0.0)) < TOL
+    # entries whose pre-activation is within rounding of zero may clip either way; none may differ
+    # from the oracle's clip by more than the pre-activation's own rounding error
+    gx = ops.conv2d_backward_data(_dev(gy), _dev(w), x.shape, relu_mask=_dev(below)).cpu().numpy()
+    refg = ocpu.conv2d_bwd_data(gy, w, x.shape) * (below > 0)
+    assert relinf(gx, refg) < TOL
+    assert (gx[below <= 0] == 0).all()
 
 
 def test_conv_autograd_matches_torch_semantics():

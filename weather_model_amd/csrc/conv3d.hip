@@ -14,6 +14,7 @@
 // entries); the weight/bias gradient is split over n-chunks of 1024 outputs, written as float64
 // partials and combined in a fixed order (bitwise reproducible, no atomics).
 #include "common.h"
+#include "conv_internal.h"
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -2288,6 +2289,10 @@ extern "C" int wm_conv3d_fwd_f32(const float *x, const float *w, const float *b,
     const int Ntot = B * d.OD * d.OH * d.OW;
     hipStream_t st = (hipStream_t)stream;
     const int ot = (Cout + 15) / 16;
+    if (D == 1 && kD == 1) {      // large 2-D grids: input rows staged through an LDS ring
+        const int rc = wm_conv_ring_launch(0, x, w, b, y, B, Cin, H, W, Cout, kH, kW, relu, st);
+        if (rc != 0) return rc < 0 ? rc : WM_OK;
+    }
     if (Ntot >= 16 * WIDE_TILES * 2 * wm_num_cus()) {          // enough tiles for two waves of blocks
         const int wblocks = (Ntot + 16 * WIDE_TILES - 1) / (16 * WIDE_TILES);
         const int otk = ot == 3 ? 4 : ot;
@@ -2416,6 +2421,10 @@ static int conv3d_bwd_data_impl(const float *gy, const float *w, float *gx, cons
     const int Mtot = B * D * H * W;
     hipStream_t st = (hipStream_t)stream;
     const int ct = (Cin + 15) / 16;
+    if (D == 1 && kD == 1) {      // large 2-D grids: gy rows staged through an LDS ring, mask fused
+        const int rc = wm_conv_ring_launch(1, gy, w, mask, gx, B, Cin, H, W, Cout, kH, kW, 0, st);
+        if (rc != 0) return rc < 0 ? rc : WM_OK;
+    }
     if (Mtot >= 16 * WIDE_TILES * 2 * wm_num_cus()) {
         const int wblocks = (Mtot + 16 * WIDE_TILES - 1) / (16 * WIDE_TILES);
         const int ctk = ct == 3 ? 4 : ct;

@@ -1,0 +1,415 @@
+// 2-D multi-channel convolution (forward and input gradient) with the input rows staged through an
+// LDS ring and the weights held in registers -- BASELINE configs[3]: Conv2d(32 -> 32, 3x3) on
+// 721 x 1440 grids, the shape of the reference's conv2/conv3/conv4 layers
+// (newConvolution.py:131-133 forward, :184 loss.backward()).
+//
+// Why: the row kernels of conv3d.hip gather every MFMA operand from global memory one dword at a
+// time (288 gathers per 64-output unit at 32 channels, each input element fetched kH*kW times
+// through L1/L2); rocprof's PMC pass put the backward-data kernel's HBM traffic at 2.35x its
+// algorithmic bytes (profiles/r02/pmc_traffic.json).  Here an input element is fetched ONCE per
+// workgroup with 16-byte loads and every input operand comes from LDS:
+//   * a four-wave workgroup walks a column stripe (64 output columns of one image) downwards, two
+//     output rows per round -- wave (r, c) owns output row 2*round + r and output channels
+//     16c .. 16c+15; two such workgroups share a CU and run out of phase, so one's stores, refill
+//     and barrier overlap the other's MFMAs (an eight-wave workgroup with one barrier per round
+//     ran its two waves per SIMD in lockstep: 100 TFLOP/s, a third of every round with the MFMA
+//     pipe idle -- in-kernel stamps);
+//   * the kH + 1 input rows a round needs (all input channels, 68 columns) live in a ring of
+//     kH + 3 row slots; the two rows the NEXT round adds are loaded into registers at the start of
+//     the round and written to their slots after the round's MFMAs -- one barrier per round;
+//   * out-of-range rows and columns (the zero padding of the input gradient) are zeros in LDS, so
+//     the inner loop has no masked variant;
+//   * a lane reads its operand window with two ds_read_b128 (columns 4j .. 4j+7 of input channel
+//     4*cg + g): register q + kw of the window is the B operand of tap kw for the output columns
+//     {4j + q}, so the two reads feed kW * 4 MFMAs, and a lane ends up with four CONSECUTIVE
+//     output columns per channel -- one 16-byte store;
+//   * the wave's kH * kW * Cin/4 A operands (its 16 output channels' weights) are loaded once into
+//     registers: the step loop is fully unrolled for the instantiated (kH, kW, Cin/4);
+//   * the rounds of all stripes are one linear range split evenly over the workgroups (a stripe
+//     boundary inside a range costs one synchronous refill of the ring).
+// The input gradient is the same computation on gy with the kernel flipped and the roles of the
+// channel counts swapped (ph = kH - 1, pw = kW - 1 rows/columns of zero padding).
+// Shapes outside the instantiated set keep the row kernels of conv3d.hip.
+#include <mutex>
+
+#include "common.h"
+#include "conv_internal.h"
+
+namespace {
+
+constexpr int RG_SEG = 64;                 // output columns per wave
+constexpr int RG_ROWS = 2;                 // output rows per round
+constexpr int RG_PITCH = 68;               // staged columns per input row (window 4j .. 4j+7, j < 16)
+constexpr int RG_GR = RG_PITCH / 4;        // 16-byte granules per staged row
+constexpr int RG_NT = 256;
+#ifndef RG_WPC
+#define RG_WPC 2                           // workgroups per CU the kernel is compiled and launched for
+#endif
+
+struct RingDims {
+    int B, Ci, Co, Hin, Win, Hout, Wout, ph, pw;
+    int segs, rpc;      // column stripes per image, rounds per stripe
+    int rounds;         // B * segs * rpc
+    int wcin, wcout;    // the weight tensor's own (Cin, Cout)
+    int relu;
+};
+
+__device__ __forceinline__ f32x4 mma4(float a, float b, f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+#ifdef RG_STAMPS
+#define RG_STAMP(i_, t_) { const long long n_ = clock64(); st_acc[i_] += n_ - t_; t_ = n_; }
+#else
+#define RG_STAMP(i_, t_)
+#endif
+
+template <int KH, int KW, int CIG, bool BWD>
+__global__ __launch_bounds__(RG_NT, RG_WPC) void conv_ring_kernel(const float *__restrict__ in,
+                                                            const float *__restrict__ w,
+                                                            const float *__restrict__ aux,   // bias (fwd) / ReLU mask (bwd) or null
+                                                            float *__restrict__ out, RingDims d)
+{
+    constexpr int NSLOT = KH + 3, CIP = 4 * CIG, SLOT_WORDS = CIP * RG_PITCH, S = KH * CIG;
+    constexpr int GI = RG_GR - 2;                                        // interior granules per row
+    constexpr int MAXF = (RG_ROWS * CIP * GI + RG_NT - 1) / RG_NT;      // staged per thread and round
+    constexpr int MAXB = (RG_ROWS * CIP * 2 + RG_NT - 1) / RG_NT;
+    extern __shared__ __align__(16) float ring[];                       // [NSLOT][CIP][RG_PITCH]
+#if defined(RG_STAMPS) || defined(RG_CLOCK)
+    const long long wk_entry = wall_clock64();
+#endif
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wrow = wave >> 1, wcg = wave & 1;
+
+    for (int e = tid * 4; e < NSLOT * SLOT_WORDS; e += RG_NT * 4) wm_store4(ring + e, (f32x4){0.f, 0.f, 0.f, 0.f});
+
+    // ---- this wave's A operands: lane (i = lane & 15, g) holds W[out channel 16 wcg + i]
+    // [contraction channel 4 cg + g][tap]; the input gradient swaps the channel roles and flips
+    // the taps
+    float wr[KH][CIG][KW];
+#pragma unroll
+    for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+        for (int cg = 0; cg < CIG; ++cg)
+#pragma unroll
+            for (int kw = 0; kw < KW; ++kw) {
+                const int m = 16 * wcg + j, ci = 4 * cg + g;
+                const int o = BWD ? ci : m, c = BWD ? m : ci;
+                const int a = BWD ? KH - 1 - kh : kh, b = BWD ? KW - 1 - kw : kw;
+                wr[kh][cg][kw] = (o < d.wcout && c < d.wcin) ? w[((o * d.wcin + c) * KH + a) * KW + b] : 0.0f;
+            }
+
+    // ---- this thread's share of a two-row refill.  Interior granules (1 .. 15 of a staged row:
+    // their columns are always inside the image) are one 16-byte load each; the two border granules
+    // (0 and 16: the image's first or last column can fall inside them) are four dword loads with
+    // clamped columns.  Every load is unconditional from a clamped, in-range address, and rows or
+    // columns outside the image become zeros when the staged registers are written to LDS: a
+    // conditional load makes hipcc merge values across branches, and the merged registers then
+    // wait for each load in turn.
+    const int n_int = RG_ROWS * d.Ci * GI, n_brd = RG_ROWS * d.Ci * 2;
+    int i_row[MAXF], i_lds[MAXF], i_glb[MAXF];
+#pragma unroll
+    for (int f = 0; f < MAXF; ++f) {
+        const int e = tid + f * RG_NT;
+        const int r = e / (d.Ci * GI), rem = e - r * (d.Ci * GI), ci = rem / GI, gc = 1 + rem - ci * GI;
+        i_row[f] = e < n_int ? r : -1;
+        i_lds[f] = e < n_int ? ci * RG_PITCH + 4 * gc : 0;
+        i_glb[f] = e < n_int ? ci * d.Hin * d.Win + 4 * gc : 4;
+    }
+    int b_row[MAXB], b_lds[MAXB], b_glb[MAXB], b_col[MAXB];
+#pragma unroll
+    for (int f = 0; f < MAXB; ++f) {
+        const int e = tid + f * RG_NT;
+        const int r = e / (2 * d.Ci), rem = e - r * (2 * d.Ci), ci = rem >> 1, gc = (rem & 1) ? RG_GR - 1 : 0;
+        b_row[f] = e < n_brd ? r : -1;
+        b_lds[f] = e < n_brd ? ci * RG_PITCH + 4 * gc : 0;
+        b_glb[f] = e < n_brd ? ci * d.Hin * d.Win : 0;
+        b_col[f] = 4 * gc;
+    }
+    const size_t in_img = (size_t)d.Ci * d.Hin * d.Win, out_img = (size_t)d.Co * d.Hout * d.Wout;
+    const size_t out_ch = (size_t)d.Hout * d.Wout;
+
+    float bv[4];
+    bool chok[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int ch = 16 * wcg + 4 * g + r;
+        chok[r] = ch < d.Co;
+        bv[r] = (!BWD && aux && ch < d.Co) ? aux[ch] : 0.0f;
+    }
+    __syncthreads();
+
+    const int r_begin = (int)((long long)d.rounds * blockIdx.x / gridDim.x);
+    const int r_end = (int)((long long)d.rounds * (blockIdx.x + 1) / gridDim.x);
+
+    // per stripe: a base pointer per staged granule (row offsets are added per round as scalars),
+    // the clamped column offsets and validity bits of the border granules, the four output pointers
+    // (32-bit offsets from bases that are uniform over the workgroup: one register per address)
+    const float *inb = in;
+    float *outb = out;
+    int ip[MAXF], bofs[MAXB][4], op4[4];
+    bool bok[MAXB][4];
+    f4u istage[MAXF];
+    float bstage[MAXB][4];
+
+    // loads the two rows v0, v0+1 (virtual rows: input row = v - ph) of the current stripe
+    auto fetch = [&](int v0) {
+        const int r0 = min(max(v0 - d.ph, 0), d.Hin - 1) * d.Win, r1 = min(max(v0 + 1 - d.ph, 0), d.Hin - 1) * d.Win;
+#pragma unroll
+        for (int f = 0; f < MAXF; ++f) istage[f] = *reinterpret_cast<const f4u *>(inb + (ip[f] + (i_row[f] > 0 ? r1 : r0)));
+#pragma unroll
+        for (int f = 0; f < MAXB; ++f) {
+            const int ro = b_row[f] > 0 ? r1 : r0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bstage[f][e] = inb[bofs[f][e] + ro];
+        }
+    };
+    auto commit = [&](int v0) {
+        const bool ok0 = (unsigned)(v0 - d.ph) < (unsigned)d.Hin, ok1 = (unsigned)(v0 + 1 - d.ph) < (unsigned)d.Hin;
+        const int s0 = (v0 % NSLOT) * SLOT_WORDS, s1 = ((v0 + 1) % NSLOT) * SLOT_WORDS;
+#pragma unroll
+        for (int f = 0; f < MAXF; ++f)
+            if (i_row[f] >= 0) {
+                const bool ok = i_row[f] > 0 ? ok1 : ok0;
+                f32x4 val;
+                val.x = ok ? istage[f].x : 0.0f; val.y = ok ? istage[f].y : 0.0f;
+                val.z = ok ? istage[f].z : 0.0f; val.w = ok ? istage[f].w : 0.0f;
+                wm_store4(ring + (i_row[f] > 0 ? s1 : s0) + i_lds[f], val);
+            }
+#pragma unroll
+        for (int f = 0; f < MAXB; ++f)
+            if (b_row[f] >= 0) {
+                const bool ok = b_row[f] > 0 ? ok1 : ok0;
+                f32x4 val;
+                val.x = (ok && bok[f][0]) ? bstage[f][0] : 0.0f;
+                val.y = (ok && bok[f][1]) ? bstage[f][1] : 0.0f;
+                val.z = (ok && bok[f][2]) ? bstage[f][2] : 0.0f;
+                val.w = (ok && bok[f][3]) ? bstage[f][3] : 0.0f;
+                wm_store4(ring + (b_row[f] > 0 ? s1 : s0) + b_lds[f], val);
+            }
+    };
+
+#ifdef RG_STAMPS
+    long long st_acc[7] = {0, 0, 0, 0, 0, 0, 0};
+#endif
+#if defined(RG_STAMPS) || defined(RG_CLOCK)
+    const long long ck0 = clock64(), wk0 = wall_clock64();
+#endif
+    for (int round = r_begin; round < r_end; ++round) {
+#ifdef RG_STAMPS
+        long long st_t = clock64();
+#endif
+        const int col = round / d.rpc, rr = round - col * d.rpc;
+        if (round == r_begin || rr == 0) {
+            // ---- new stripe: addresses, synchronous refill of the live rows
+            const int b_ = col / d.segs, seg = col - b_ * d.segs;
+            const int w0 = min(seg * RG_SEG, d.Wout - RG_SEG);
+            const int c_first = w0 - d.pw;
+            inb = in + (size_t)b_ * in_img;
+            outb = out + (size_t)b_ * out_img;
+#pragma unroll
+            for (int f = 0; f < MAXF; ++f) ip[f] = i_glb[f] + c_first;
+#pragma unroll
+            for (int f = 0; f < MAXB; ++f)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = c_first + b_col[f] + e;
+                    bofs[f][e] = b_glb[f] + min(max(c, 0), d.Win - 1);
+                    bok[f][e] = (unsigned)c < (unsigned)d.Win;
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                op4[r] = (16 * wcg + 4 * g + (chok[r] ? r : 0)) * (int)out_ch + w0 + 4 * j;
+            __syncthreads();                 // the previous stripe's last round has been read
+#pragma unroll
+            for (int v = 0; v <= KH; v += RG_ROWS) {
+                fetch(RG_ROWS * rr + v);
+                commit(RG_ROWS * rr + v);
+            }
+            __syncthreads();
+        }
+        const bool more = rr + 1 < d.rpc && round + 1 < r_end;
+        const int vnext = RG_ROWS * rr + KH + 1;
+#ifndef RG_ABL_NO_FILL
+        if (more) fetch(vnext);
+#endif
+        const int h = RG_ROWS * rr + wrow;
+        const int hoff = min(h, d.Hout - 1) * d.Wout;
+        // the ReLU mask of this wave's outputs, fetched with the refill rows: loaded at store time its
+        // latency would sit between the MFMAs and the barrier of every round
+        f4u m4[4];
+        if (BWD && aux) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m4[r] = *reinterpret_cast<const f4u *>(aux + (outb - out) + (op4[r] + hoff));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        RG_STAMP(0, st_t)
+
+        if (h < d.Hout) {
+            f32x4 acc[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+            const float *bl = ring + g * RG_PITCH + 4 * j;
+            const float *brow[KH];
+            {
+                int s_ = h % NSLOT;
+#pragma unroll
+                for (int kh = 0; kh < KH; ++kh) {
+                    brow[kh] = bl + s_ * SLOT_WORDS;
+                    s_ = s_ + 1 == NSLOT ? 0 : s_ + 1;
+                }
+            }
+            f32x4 lo[2], hi[2];
+            lo[0] = wm_load4(brow[0]);
+            hi[0] = wm_load4(brow[0] + 4);
+            RG_STAMP(1, st_t)
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                if (s + 1 < S) {
+                    const float *bp = brow[(s + 1) / CIG] + ((s + 1) % CIG) * 4 * RG_PITCH;
+                    lo[(s + 1) & 1] = wm_load4(bp);
+                    hi[(s + 1) & 1] = wm_load4(bp + 4);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                {
+                    const f32x4 l_ = lo[s & 1], h_ = hi[s & 1];
+                    const float v[8] = {l_.x, l_.y, l_.z, l_.w, h_.x, h_.y, h_.z, h_.w};
+#ifdef RG_ABL_NO_MMA
+                    acc[0].x += v[0] + v[7];
+#else
+#pragma unroll
+                    for (int kw = 0; kw < KW; ++kw)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[q] = mma4(wr[s / CIG][s % CIG][kw], v[q + kw], acc[q]);
+#endif
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            RG_STAMP(2, st_t)
+#ifdef RG_STAMPS
+            __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0): the refill loads' latency, apart
+            RG_STAMP(6, st_t)
+#endif
+#ifndef RG_ABL_NO_FILL
+            // the staged rows go to LDS before the stores are issued: the wait for the loads would
+            // otherwise also wait for the stores (one counter on gfx9)
+            if (more) commit(vnext);
+#endif
+            RG_STAMP(3, st_t)
+
+            // ---- store: four consecutive columns per lane and channel
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                f4u v4;
+                v4.x = acc[0][r]; v4.y = acc[1][r]; v4.z = acc[2][r]; v4.w = acc[3][r];
+                if (BWD) {
+                    if (aux) {
+                        v4.x = m4[r].x > 0.0f ? v4.x : 0.0f;
+                        v4.y = m4[r].y > 0.0f ? v4.y : 0.0f;
+                        v4.z = m4[r].z > 0.0f ? v4.z : 0.0f;
+                        v4.w = m4[r].w > 0.0f ? v4.w : 0.0f;
+                    }
+                } else {
+                    v4.x += bv[r]; v4.y += bv[r]; v4.z += bv[r]; v4.w += bv[r];
+                    if (d.relu) {
+                        v4.x = fmaxf(v4.x, 0.0f); v4.y = fmaxf(v4.y, 0.0f);
+                        v4.z = fmaxf(v4.z, 0.0f); v4.w = fmaxf(v4.w, 0.0f);
+                    }
+                }
+#ifdef RG_ABL_NO_STORE
+                if (v4.x == 123.456f)
+#endif
+                if (chok[r]) *reinterpret_cast<f4u *>(outb + (op4[r] + hoff)) = v4;
+            }
+        } else {
+#ifndef RG_ABL_NO_FILL
+            if (more) commit(vnext);
+#endif
+        }
+        RG_STAMP(4, st_t)
+        __syncthreads();
+        RG_STAMP(5, st_t)
+    }
+#if defined(RG_STAMPS) || defined(RG_CLOCK)
+    if ((blockIdx.x == 0 || blockIdx.x == 300) && tid == 0) {
+        const long long ck = clock64() - ck0, wend = wall_clock64(), wk = wend - wk0;
+        printf("wg %3d: entry %lld  init %lld ticks, %lld cycles in %lld ticks of 10 ns = %.0f MHz, end %lld\n", (int)blockIdx.x,
+               wk_entry % 10000000, wk0 - wk_entry, ck, wk, 100.0 * ck / wk, wend % 10000000);
+    }
+#endif
+#ifdef RG_STAMPS
+    if ((blockIdx.x == 0 || blockIdx.x == 300) && (tid & 127) == 0)
+        printf("wg %d wave %d rounds %d: fetch %lld  setup %lld  loop %lld  vmwait %lld  commit %lld  store %lld  barrier %lld\n",
+               (int)blockIdx.x, wave, r_end - r_begin, st_acc[0], st_acc[1], st_acc[2], st_acc[6], st_acc[3], st_acc[4], st_acc[5]);
+#endif
+}
+
+template <int KH, int KW, int CIG, bool BWD>
+int ring_launch_as(const float *in, const float *w, const float *aux, float *out, const RingDims &d,
+                   hipStream_t st)
+{
+    constexpr size_t lds = (size_t)(KH + 3) * 4 * CIG * RG_PITCH * sizeof(float);
+    static_assert(lds * RG_WPC <= 160 * 1024, "RG_WPC workgroups per CU");
+    static std::mutex mu;
+    static bool done[64] = {};
+    int dev = 0;
+    WM_HIP(hipGetDevice(&dev));
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!done[dev & 63]) {
+            WM_HIP(hipFuncSetAttribute((const void *)conv_ring_kernel<KH, KW, CIG, BWD>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            done[dev & 63] = true;
+        }
+    }
+    int grid = wm_num_cus() * RG_WPC;
+#ifdef WM_PROBE_ENV
+    if (const char *e = getenv("WM_RING_WGS")) grid = wm_num_cus() * atoi(e);
+#endif
+    if (grid > d.rounds) grid = d.rounds;
+    hipLaunchKernelGGL((conv_ring_kernel<KH, KW, CIG, BWD>), dim3(grid), dim3(RG_NT), lds, st, in, w, aux,
+                       out, d);
+    WM_LAUNCH_CHECK("conv_ring_kernel");
+    return 1;
+}
+
+}  // namespace
+
+// 1 = launched, 0 = shape not taken (the caller goes on to its other kernels), < 0 = error.
+int wm_conv_ring_launch(int bwd, const float *in, const float *w, const float *aux, float *out, int B,
+                        int Cin, int H, int W, int Cout, int kH, int kW, int relu, hipStream_t st)
+{
+#ifdef WM_PROBE_ENV
+    if (const char *e = getenv("WM_CONV_RING"))
+        if (atoi(e) == 0) return 0;
+#endif
+    RingDims d;
+    const int OH = H - kH + 1, OW = W - kW + 1;
+    d.B = B; d.relu = relu; d.wcin = Cin; d.wcout = Cout;
+    if (bwd) {
+        d.Ci = Cout; d.Co = Cin; d.Hin = OH; d.Win = OW; d.Hout = H; d.Wout = W;
+        d.ph = kH - 1; d.pw = kW - 1;
+    } else {
+        d.Ci = Cin; d.Co = Cout; d.Hin = H; d.Win = W; d.Hout = OH; d.Wout = OW;
+        d.ph = 0; d.pw = 0;
+    }
+    // two channel groups of 16 per workgroup: 17 .. 32 output channels
+    if (d.Wout < RG_SEG || d.Co <= 16 || d.Co > 32) return 0;
+    d.segs = (d.Wout + RG_SEG - 1) / RG_SEG;
+    d.rpc = (d.Hout + RG_ROWS - 1) / RG_ROWS;
+    const long long rounds = (long long)B * d.segs * d.rpc;
+    if (rounds < 8LL * wm_num_cus() || rounds >= (1LL << 31)) return 0;
+    d.rounds = (int)rounds;
+    const int cig = (d.Ci + 3) / 4;
+#define RING_CASE(KH_, KW_, CIG_)                                                              \
+    if (kH == KH_ && kW == KW_ && cig == CIG_)                                                 \
+        return bwd ? ring_launch_as<KH_, KW_, CIG_, true>(in, w, aux, out, d, st)              \
+                   : ring_launch_as<KH_, KW_, CIG_, false>(in, w, aux, out, d, st);
+    RING_CASE(3, 3, 8)
+    RING_CASE(3, 3, 4)
+#undef RING_CASE
+    return 0;
+}
