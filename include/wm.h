@@ -374,7 +374,9 @@ int wm_comm_destroy(void);
 int wm_synth_uniform_f32(float *out, int64_t count, uint64_t seed, uint64_t offset,
                          float lo, float hi, void *stream);
 /* Rows [row_offset, row_offset+n) of the synthetic regression problem of SURVEY.md 8d:
- * X ~ U(0,1) (dist 0) or N(0,1) (dist 1); Y = X beta + intercept + N(0, noise^2).
+ * X ~ U(0,1) (dist 0), N(0,1) (dist 1) or U(0,1) from paired draws (dist 2: two 24-bit uniforms per
+ * hash, the stream of weather_model_amd/synth.py uniform_paired01 -- half the generator's integer
+ * work, used where generation is inside the timed region); Y = X beta + intercept + N(0, noise^2).
  * beta: device, F x P float32. */
 int wm_synth_regression_f32(float *X, float *Y, int64_t n, int F, int P, uint64_t seed,
                             uint64_t row_offset, const float *beta, float intercept,

@@ -120,6 +120,18 @@ def test_device_generator_matches_host_generator():
     Xh, Yh, _ = synth.regression_problem(5000, 16, 1, seed=1)
     assert np.array_equal(Xd.cpu().numpy(), Xh)
     assert np.abs(Yd.cpu().numpy() - Yh).max() < 1e-4       # Box-Muller: float32 vs float64 libm
+    # paired draws (dist 2): the row kernel (F = 64, 16), the generic kernel (F = 6, P = 2), an odd
+    # row offset -- bit for bit the host stream
+    for F, P, off in ((64, 1, 0), (16, 1, 12345), (6, 2, 7)):
+        beta = synth.normal(1003, (F, P))
+        Xd, Yd = ops.synth_regression(3000, F, P, seed=3, beta=torch.from_numpy(beta), dist="uniform_paired",
+                                      row_offset=off)
+        Xh, Yh, _ = synth.regression_problem(3000, F, P, seed=3, dist="uniform_paired", row_offset=off)
+        assert np.array_equal(Xd.cpu().numpy(), Xh)
+        assert np.abs(Yd.cpu().numpy() - Yh).max() < 1e-4
+    u = synth.uniform_paired01(5, 200_000)
+    assert 0.0 <= u.min() and u.max() < 1.0 and abs(u.mean() - 0.5) < 5e-3
+    assert abs(np.corrcoef(u[0::2], u[1::2])[0, 1]) < 1e-2      # the two draws of a hash
 
 
 def test_full_size_property_recovers_planted_coefficients():

@@ -17,6 +17,16 @@ __device__ __forceinline__ uint64_t hash64(uint64_t seed, uint64_t idx)
 
 __device__ __forceinline__ float u01(uint64_t z) { return (float)(z >> 40) * 0x1.0p-24f; }
 
+// dist 2, "paired uniform": TWO 24-bit draws per hash -- elements 2k and 2k+1 take bits 63..40 and
+// 39..16 of hash64(seed, k).  Half the 64-bit multiplies per float: the row generator of config 5
+// was bound by them (3.9 ms per 5e7 x 64 chunk against 2.3 ms for the Gram pass it feeds).
+__device__ __forceinline__ float u01_lo(uint64_t z) { return (float)((z >> 16) & 0xFFFFFFull) * 0x1.0p-24f; }
+__device__ __forceinline__ float u01_paired(uint64_t seed, uint64_t e)
+{
+    const uint64_t z = hash64(seed, e >> 1);
+    return (e & 1) ? u01_lo(z) : u01(z);
+}
+
 __device__ __forceinline__ float gauss(uint64_t z)
 {
     const float u1 = ((float)(z >> 40) + 1.0f) * 0x1.0p-24f;            // (0,1]
@@ -44,8 +54,8 @@ __global__ __launch_bounds__(BLOCK) void synth_regression_kernel(
         for (int p = 0; p < P; ++p) {
             float s = intercept;
             for (int f = 0; f < F; ++f) {
-                const uint64_t z = hash64(seed, gr * (uint64_t)F + f);
-                const float xv = dist ? gauss(z) : u01(z);
+                const uint64_t e = gr * (uint64_t)F + f;
+                const float xv = dist == 2 ? u01_paired(seed, e) : (dist ? gauss(hash64(seed, e)) : u01(hash64(seed, e)));
                 if (p == 0) X[r * F + f] = xv;
                 s = fmaf(xv, beta[f * P + p], s);
             }
@@ -71,23 +81,36 @@ __global__ __launch_bounds__(BLOCK) void synth_regression_rows_kernel(
     const long long wave = (long long)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
     const long long nwaves = (long long)gridDim.x * (BLOCK / 64);
     const f32x4 b = *reinterpret_cast<const f32x4 *>(beta + 4 * g);
-    for (long long r0 = wave * RPW; r0 < n; r0 += nwaves * RPW) {
-        const long long r = min(r0 + rl, n - 1);      // clamped: every lane takes part in the sum
-        const uint64_t gr = row_offset + (uint64_t)r;
-        const uint64_t e0 = gr * (uint64_t)F + (uint64_t)(4 * g);
-        f32x4 xv;
+    // a wave owns blocks of 64 consecutive rows (16 KiB of X at F = 64): G iterations of RPW rows,
+    // and lane (g, rl) keeps the row sum of iteration g -- so each lane draws the Box-Muller noise
+    // of exactly ONE row per block instead of every lane sitting through lane 0's logf / cospif on
+    // every iteration
+    for (long long blk = wave; blk * 64 < n; blk += nwaves) {
+        float mine = 0.0f;
+#pragma unroll(G <= 16 ? G : 1)
+        for (int it = 0; it < G; ++it) {
+            const long long r_ = blk * 64 + it * RPW + rl;
+            const long long r = min(r_, n - 1);       // clamped: every lane takes part in the sum
+            const uint64_t e0 = (row_offset + (uint64_t)r) * (uint64_t)F + (uint64_t)(4 * g);
+            f32x4 xv;
+            if (dist == 2) {                          // e0 is a multiple of 4: two hashes, four floats
+                const uint64_t za = hash64(seed, e0 >> 1), zb = hash64(seed, (e0 >> 1) + 1);
+                xv[0] = u01(za); xv[1] = u01_lo(za); xv[2] = u01(zb); xv[3] = u01_lo(zb);
+            } else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint64_t z = hash64(seed, e0 + k);
-            xv[k] = dist ? gauss(z) : u01(z);
-        }
-        float s = fmaf(xv[3], b[3], fmaf(xv[2], b[2], fmaf(xv[1], b[1], xv[0] * b[0])));
+                for (int k = 0; k < 4; ++k) {
+                    const uint64_t z = hash64(seed, e0 + k);
+                    xv[k] = dist ? gauss(z) : u01(z);
+                }
+            }
+            float s = fmaf(xv[3], b[3], fmaf(xv[2], b[2], fmaf(xv[1], b[1], xv[0] * b[0])));
 #pragma unroll
-        for (int o = G / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-        if (r0 + rl < n) {
-            __builtin_nontemporal_store(xv, reinterpret_cast<f32x4 *>(X + r * F + 4 * g));
-            if (g == 0) Y[r] = (s + intercept) + noise * gauss(hash64(seed + 2000, gr));
+            for (int o = G / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            if (r_ < n) __builtin_nontemporal_store(xv, reinterpret_cast<f32x4 *>(X + r * F + 4 * g));
+            mine = it == g ? s : mine;
         }
+        const long long row = blk * 64 + g * RPW + rl;
+        if (row < n) Y[row] = (mine + intercept) + noise * gauss(hash64(seed + 2000, row_offset + (uint64_t)row));
     }
 }
 
@@ -125,7 +148,7 @@ extern "C" int wm_synth_regression_f32(float *X, float *Y, int64_t n, int F, int
     const int G = F / 4;
     if (P == 1 && F % 4 == 0 && G <= 64 && (G & (G - 1)) == 0 &&
         (((uintptr_t)X | (uintptr_t)beta) & 15) == 0) {
-        const long long waves = (n + 64 / G - 1) / (64 / G);
+        const long long waves = (n + 63) / 64;          // one wave per block of 64 rows
         const int grid = grid_for(waves * 64);
 #define WM_SYNTH_ROWS(G_)                                                                      \
     hipLaunchKernelGGL(synth_regression_rows_kernel<G_>, dim3(grid), dim3(BLOCK), 0,           \

@@ -747,6 +747,9 @@ def synth_uniform(shape, seed, lo=0.0, hi=1.0, offset=0, device="cuda"):
     return out
 
 
+SYNTH_DIST = {"uniform": 0, "normal": 1, "uniform_paired": 2}
+
+
 def synth_regression(n, F, P, seed, beta, intercept=0.5, noise=0.01, dist="uniform",
                      row_offset=0, device="cuda"):
     beta = _req(beta.to(device), "beta")
@@ -755,7 +758,7 @@ def synth_regression(n, F, P, seed, beta, intercept=0.5, noise=0.01, dist="unifo
     with torch.cuda.device(X.device):
         _lib.check(_lib.lib().wm_synth_regression_f32(
             X.data_ptr(), Y.data_ptr(), n, F, P, int(seed), int(row_offset), beta.data_ptr(),
-            float(intercept), float(noise), 0 if dist == "uniform" else 1, _stream()))
+            float(intercept), float(noise), SYNTH_DIST[dist], _stream()))
     return X, Y
 
 

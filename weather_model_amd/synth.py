@@ -34,6 +34,17 @@ def uniform01(seed: int, count: int, offset: int = 0) -> np.ndarray:
     return ((z >> np.uint64(40)).astype(np.float32)) * np.float32(2.0 ** -24)
 
 
+def uniform_paired01(seed: int, count: int, offset: int = 0) -> np.ndarray:
+    """float32 U[0,1), two 24-bit draws per hash (csrc/synth.hip, dist 2): elements 2k and 2k+1 take
+    bits 63..40 and 39..16 of hash64(seed, k).  A different stream from uniform01."""
+    idx = np.arange(offset, offset + count, dtype=np.uint64)
+    z = hash64(seed, idx >> np.uint64(1))
+    hi = z >> np.uint64(40)
+    lo = (z >> np.uint64(16)) & np.uint64(0xFFFFFF)
+    bits = np.where((idx & np.uint64(1)).astype(bool), lo, hi)
+    return bits.astype(np.float32) * np.float32(2.0 ** -24)
+
+
 def uniform(seed: int, shape, lo=0.0, hi=1.0, offset: int = 0) -> np.ndarray:
     n = int(np.prod(shape))
     u = uniform01(seed, n, offset)
@@ -59,6 +70,8 @@ def regression_problem(n: int, F: int, P: int = 1, seed: int = 1, dist: str = "u
     beta = normal(seed + 1000, (F, P)).astype(np.float64)
     if dist == "uniform":
         X = uniform(seed, (n, F), offset=row_offset * F)
+    elif dist == "uniform_paired":
+        X = uniform_paired01(seed, n * F, offset=row_offset * F).reshape(n, F)
     else:
         X = normal(seed, (n, F), offset=row_offset * F)
     eps = normal(seed + 2000, (n, P), std=noise, offset=row_offset * P)
