@@ -33,10 +33,12 @@ MFMA_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: FP32 matrix 157.3 TFLOP/s
 EXEC_FLOPS_PER_SAMPLE = 101.6e6 * 2048 / 1038240    # model_kernel<1>: MFMAs issued per step
 
 
-PMC_FILE = os.path.join("profiles", "r02", "pmc_traffic.json")
+PMC_FILE = os.path.join("profiles", "r03", "pmc_traffic.json")
+PMC_FALLBACKS = (os.path.join("profiles", "r02", "pmc_traffic.json"),
+                 os.path.join("profiles", "r01", "pmc_traffic.json"))
 
 
-def pmc_traffic(kernels, default_shape):
+def pmc_traffic(kernels, default_shape, path=None):
     """HBM-side bytes per launch of `kernels` from the committed PMC passes (tools/pmc_bench.sh +
     tools/pmc_summarise.py, FETCH_SIZE x2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes).  The
     counters cannot be collected inside a timed run, so this is the figure of the STORED profile
@@ -44,7 +46,7 @@ def pmc_traffic(kernels, default_shape):
     when the workload has the profiled (default) shape."""
     if not default_shape:
         return None
-    for path in (PMC_FILE, os.path.join("profiles", "r01", "pmc_traffic.json")):
+    for path in ((path,) if path else (PMC_FILE,) + PMC_FALLBACKS):
         try:
             with open(os.path.join(ROOT, path)) as fh:
                 table = json.load(fh)["kernels"]
@@ -54,10 +56,10 @@ def pmc_traffic(kernels, default_shape):
     return None
 
 
-def pmc_source(kernels, default_shape):
+def pmc_source(kernels, default_shape, path=None):
     if not default_shape:
         return None
-    for path in (PMC_FILE, os.path.join("profiles", "r01", "pmc_traffic.json")):
+    for path in ((path,) if path else (PMC_FILE,) + PMC_FALLBACKS):
         try:
             with open(os.path.join(ROOT, path)) as fh:
                 table = json.load(fh)["kernels"]
@@ -425,7 +427,10 @@ def run_gram(F, n_rows, steps, warmup, rank, world, cpu_base, P=1, dist="uniform
     if sevs:
         res["solve_ms_avg"] = float(np.mean([a.elapsed_time(c) for a, c in sevs]))
     kname = gram_kernel_name(F, P)
-    default_shape = (F, P, n_rows, dist) == (16, 1, 100_000_000, "uniform")
+    # the shapes whose launches are in the stored PMC passes of the default line
+    default_shape = (F, P, n_rows) in ((16, 1, 100_000_000), (2, 1, 400_000_000), (432, 216, 1_000_000))
+    pkey = {"gram_small_kernel": f"gram_small_kernel<{F}, {P}>",
+            "gram_syrk_kernel": "gram_syrk_kernel<true, 2>"}.get(kname, kname)
     gbs = bytes_per_row * n_rows / kavg / 1e9
     tf = flops_per_row * n_rows / kavg / 1e12
     if flops_per_row / bytes_per_row < MFMA_F32_PEAK_TF * 1e3 / HBM_PEAK_GBS:
@@ -435,8 +440,8 @@ def run_gram(F, n_rows, steps, warmup, rank, world, cpu_base, P=1, dist="uniform
         res["roofline"] = {"bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TF,
                            "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF,
                            "hbm_GBs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS}
-    res["roofline"].update({"traffic": pmc_traffic([kname], default_shape),
-                            "traffic_source": pmc_source([kname], default_shape),
+    res["roofline"].update({"traffic": pmc_traffic([pkey], default_shape),
+                            "traffic_source": pmc_source([pkey], default_shape),
                             "kernel": kname, "algorithmic_bytes_per_row": bytes_per_row,
                             "algorithmic_flops_per_row": flops_per_row,
                             "TFLOPs_algorithmic": tf})
@@ -833,8 +838,8 @@ def run_model(steps, warmup, rank, world, cpu_base, B=721 * 1440):
                                   "192->64->6 head) fwd+bwd+Adam, 1038240 grid points per GPU per step"},
            "roofline": {"bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF,
                         "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF,
-                        "traffic": pmc_traffic(["model_kernel<1>"], B == 721 * 1440),
-                        "traffic_source": pmc_source(["model_kernel<1>"], B == 721 * 1440),
+                        "traffic": pmc_traffic(["model_kernel<1, false>"], B == 721 * 1440),
+                        "traffic_source": pmc_source(["model_kernel<1, false>"], B == 721 * 1440),
                         "kernel": "model_kernel<1>", "algorithmic_flops_per_sample": flops,
                         # the kernel issues 101.6 M v_mfma_f32_16x16x4_f32 (2048 flop each) per
                         # 1 038 240-sample step: the start/end rows of every conv input are rank-1
@@ -932,6 +937,11 @@ def conv_stack_cpu_library(ws, bs, x1, g1, relu, reps=5):
                       f"weights, biases) on CPU tensors, {nthr} threads, median of {n}"}
 
 
+CONV32_KERNELS = ["conv_ring_kernel<3, 3, 8, false>", "conv_ring_kernel<3, 3, 8, true>",
+                  "conv3d_bwd_wb_staged_kernel<1, 9, 2>"]
+CONV32_PMC = os.path.join("profiles", "r03", "pmc_traffic_conv32.json")
+
+
 def run_conv32(steps, warmup, rank, world, cpu_base, N=8, C=32, H=721, W=1440):
     """BASELINE configs[3] read literally (4b): one Conv(32->32, 3x3) layer on (N,32,721,1440),
     forward + backward(data, weight, bias) -- the implicit-GEMM MFMA kernels."""
@@ -993,11 +1003,14 @@ def run_conv32(steps, warmup, rank, world, cpu_base, N=8, C=32, H=721, W=1440):
                                    f"({N},{C},{H},{W}) per GPU"},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF,
                          "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF,
-                         "traffic": pmc_traffic(["conv3d_fwd_rows_kernel<2>",
-                                                 "conv3d_bwd_data_rows_kernel<2>",
-                                                 "conv3d_bwd_wb_staged_kernel<1, 9, 2>"],
-                                                (N, C, H, W) == (8, 32, 721, 1440)),
-                         "kernel": "conv3d_fwd_rows_kernel + conv3d_bwd_data_rows_kernel + "
+                         # (the PMC passes of THIS workload alone: in the full line's passes the ring
+                         # kernel's average also holds the masked calls of conv32x3)
+                         "traffic": pmc_traffic(CONV32_KERNELS, (N, C, H, W) == (8, 32, 721, 1440),
+                                                CONV32_PMC),
+                         "traffic_source": pmc_source(CONV32_KERNELS,
+                                                      (N, C, H, W) == (8, 32, 721, 1440), CONV32_PMC),
+                         "algorithmic_bytes": 4.0 * N * C * (3 * H * W + 3 * (H - 2) * (W - 2)),
+                         "kernel": "conv_ring_kernel<3,3,8,false> + conv_ring_kernel<3,3,8,true> + "
                                    "conv3d_bwd_wb_staged_kernel",
                          "algorithmic_flops_per_point_per_pass": 2 * C * C * 9,
                          "TFLOPs": {k: flops_pass / (v * 1e-3) / 1e12 for k, v in ms.items()},
@@ -1182,7 +1195,7 @@ def run_fields(steps, warmup, rank, world, cpu_base):
                     "roofline": {"bound": "hbm", "achieved": 24 * nv * crow / k_cub / 1e9,
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": 24 * nv * crow / k_cub / 1e9 / HBM_PEAK_GBS,
-                                 "traffic": None, "kernel": "gather_cubes_kernel<true>",
+                                 "traffic": pmc_traffic(["gather_cubes_kernel<true, 4>"], True), "traffic_source": pmc_source(["gather_cubes_kernel<true, 4>"], True), "kernel": "gather_cubes_kernel<true, 4>",
                                  "algorithmic_bytes_per_row": 24 * nv},
                     "config": {"workload": f"regression rows [x(t) | x(t+6) ; x(t+3)]: {crow} rows "
                                            f"of {nv} variables, cube 1, batches of {bs}, region walk "
