@@ -937,7 +937,7 @@ def conv_stack_cpu_library(ws, bs, x1, g1, relu, reps=5):
                       f"weights, biases) on CPU tensors, {nthr} threads, median of {n}"}
 
 
-CONV32_KERNELS = ["conv_ring_kernel<3, 3, 8, false>", "conv_ring_kernel<3, 3, 8, true>",
+CONV32_KERNELS = ["conv3d_fwd_rows_kernel<2>", "conv_ring_kernel<3, 3, 8, true>",
                   "conv3d_bwd_wb_staged_kernel<1, 9, 2>"]
 CONV32_PMC = os.path.join("profiles", "r03", "pmc_traffic_conv32.json")
 
@@ -1010,7 +1010,7 @@ def run_conv32(steps, warmup, rank, world, cpu_base, N=8, C=32, H=721, W=1440):
                          "traffic_source": pmc_source(CONV32_KERNELS,
                                                       (N, C, H, W) == (8, 32, 721, 1440), CONV32_PMC),
                          "algorithmic_bytes": 4.0 * N * C * (3 * H * W + 3 * (H - 2) * (W - 2)),
-                         "kernel": "conv_ring_kernel<3,3,8,false> + conv_ring_kernel<3,3,8,true> + "
+                         "kernel": "conv3d_fwd_rows_kernel<2> + conv_ring_kernel<3,3,8,true> + "
                                    "conv3d_bwd_wb_staged_kernel",
                          "algorithmic_flops_per_point_per_pass": 2 * C * C * 9,
                          "TFLOPs": {k: flops_pass / (v * 1e-3) / 1e12 for k, v in ms.items()},

@@ -144,8 +144,9 @@ def test_conv32_full_size_adjoint_identities():
     (2, 16, 200, 400, 24, 3, 3),  # multi-channel, > 131072 outputs: wide MFMA kernel, ragged Cout
     (1, 20, 140, 1000, 40, 2, 3), # wide MFMA kernel, ragged Cin, three channel tiles
     (2, 16, 600, 900, 24, 3, 3),  # > 2^20 outputs: the persistent wide weight-gradient kernel
-    # the LDS-ring kernel (conv_ring.hip): ragged channel counts on both sides, kernels up to 5 x 4,
-    # the reference's (3, 1) orientation, one 64-column stripe exactly, three channel tiles, one tile
+    # large multi-channel grids (row kernels; 3x3 with 17..32 output channels on the input-gradient
+    # side also takes conv_ring.hip): ragged channel counts, kernels up to 5 x 4, the reference's
+    # (3, 1) orientation, one 64-column stripe exactly, three channel tiles, one tile
     (4, 8, 140, 330, 24, 3, 3), (4, 6, 120, 300, 20, 5, 4), (6, 16, 200, 128, 32, 3, 1),
     (20, 32, 130, 66, 32, 3, 3), (5, 12, 100, 300, 48, 3, 3), (5, 20, 100, 300, 10, 2, 2),
     (3, 33, 150, 200, 35, 1, 2),
@@ -209,6 +210,22 @@ def test_conv_fused_relu_paths_vs_oracle(shape):
     refg = ocpu.conv2d_bwd_data(gy, w, x.shape) * (below > 0)
     assert relinf(gx, refg) < TOL
     assert (gx[below <= 0] == 0).all()
+
+
+def test_conv_ring_forward_and_masked_paths_in_a_subprocess():
+    """conv_ring.hip by default takes only the unmasked input gradient (where it is the faster
+    kernel); its forward and fused-mask variants are reached with WM_CONV_RING=all, which the
+    library reads once per process -- so they are checked in ONE child process
+    (tests/ring_paths_check.py: the ring shapes of the tests above against the float64 oracle)."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, WM_CONV_RING="all")
+    r = subprocess.run([sys.executable, os.path.join(here, "ring_paths_check.py")], env=env,
+                       capture_output=True, text=True, timeout=170)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "ring paths ok" in r.stdout
 
 
 def test_conv_autograd_matches_torch_semantics():

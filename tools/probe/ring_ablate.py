@@ -22,7 +22,9 @@ def build():
 
 def run():
     import torch
-    N, C, H, W = 8, 32, 721, 1440
+    N, C = 8, 32
+    H, W = int(os.environ.get('RG_H', 721)), int(os.environ.get('RG_W', 1440))
+    RELU = int(os.environ.get('RG_RELU', 0))
     x = torch.rand(N, C, H, W, device="cuda") - 0.5
     w = (torch.rand(C, C, 3, 3, device="cuda") - 0.5) / 17
     b = torch.rand(C, device="cuda") - 0.5
@@ -38,7 +40,7 @@ def run():
     st = torch.cuda.current_stream().cuda_stream
 
     def fwd():
-        assert L.wm_conv2d_fwd_f32(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), N, C, H, W, C, 3, 3, 0, st) == 0
+        assert L.wm_conv2d_fwd_f32(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), N, C, H, W, C, 3, 3, RELU, st) == 0
 
     def bwd():
         assert L.wm_conv2d_bwd_data_f32(gy.data_ptr(), w.data_ptr(), gx.data_ptr(), N, C, H, W, C, 3, 3, st) == 0
@@ -60,6 +62,7 @@ def run():
     msg = f"{os.path.basename(OUT):40s} fwd {tf:6.3f} ms {flops * N * (H - 2) * (W - 2) / tf / 1e9:6.1f} TF   bwd_data {tb:6.3f} ms {flops * N * H * W / tb / 1e9:6.1f} TF  masked {tm:6.3f} ms"
     if not EXTRA or all(e.startswith("-DWM_") or e.startswith("-DRG_OPT") for e in EXTRA):
         ref = torch.nn.functional.conv2d(x[:1], w, b)
+        if RELU: ref = ref.clamp_min(0)
         e1 = float((y[:1] - ref).abs().max() / ref.abs().max())
         refg = torch.nn.grad.conv2d_input((1, C, H, W), w, gy[:1])
         e2 = float((gx[:1] - refg).abs().max() / refg.abs().max())

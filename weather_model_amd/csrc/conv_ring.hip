@@ -30,6 +30,7 @@
 // The input gradient is the same computation on gy with the kernel flipped and the roles of the
 // channel counts swapped (ph = kH - 1, pw = kW - 1 rows/columns of zero padding).
 // Shapes outside the instantiated set keep the row kernels of conv3d.hip.
+#include <cstdlib>
 #include <mutex>
 
 #include "common.h"
@@ -382,10 +383,18 @@ int ring_launch_as(const float *in, const float *w, const float *aux, float *out
 int wm_conv_ring_launch(int bwd, const float *in, const float *w, const float *aux, float *out, int B,
                         int Cin, int H, int W, int Cout, int kH, int kW, int relu, hipStream_t st)
 {
-#ifdef WM_PROBE_ENV
-    if (const char *e = getenv("WM_CONV_RING"))
-        if (atoi(e) == 0) return 0;
-#endif
+    // Measured on config 4b and the three layer shapes of its stack (tools/probe/ring_ablate.py, one
+    // box, A-B): input gradient 1.21-1.23 ms here against 1.24-1.27 with the row kernel, but forward
+    // 1.21-1.23 against 1.20, and the input gradient with the fused ReLU mask 1.38-1.46 against
+    // 1.34-1.38.  So by default only the unmasked input gradient comes here; WM_CONV_RING=all sends
+    // the other two as well (the tests do, to keep them covered), WM_CONV_RING=0 none.
+    {
+        static const int mode = [] {
+            const char *e = getenv("WM_CONV_RING");
+            return !e ? 1 : (e[0] == 'a' ? 2 : (e[0] == '0' ? 0 : 1));
+        }();
+        if (mode == 0 || (mode == 1 && (!bwd || aux))) return 0;
+    }
     RingDims d;
     const int OH = H - kH + 1, OW = W - kW + 1;
     d.B = B; d.relu = relu; d.wcin = Cin; d.wcout = Cout;
