@@ -118,8 +118,29 @@ class Conv3DModel:
             x = ops.maxpool3d(x, self.pool_channels_last)
         return x.reshape(x.shape[0], -1)
 
+    # The two conv branches (convolution.py:164-173) are independent until the concatenation and
+    # their kernels run 224-workgroup grids on 256 CUs: branch 2 goes to a second stream, forward
+    # and -- autograd runs a node's backward on its forward's stream -- backward, so the device can
+    # run a kernel of each side by side.  Also under graph capture (the side stream forks from and
+    # rejoins the capturing stream through events).
+    BRANCH_STREAMS = True
+
     def forward(self, x1, x2):
-        h = torch.cat((self._branch(x1, "1"), self._branch(x2, "2")), dim=1)
+        if self.BRANCH_STREAMS and x1.is_cuda:
+            main = torch.cuda.current_stream(x1.device)
+            side = self.__dict__.get("_side_stream")
+            if side is None or side.device != x1.device:
+                side = self._side_stream = torch.cuda.Stream(x1.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                h2 = self._branch(x2, "2")
+            h1 = self._branch(x1, "1")
+            main.wait_stream(side)
+            if not torch.cuda.is_current_stream_capturing():
+                h2.record_stream(main)
+            h = torch.cat((h1, h2), dim=1)
+        else:
+            h = torch.cat((self._branch(x1, "1"), self._branch(x2, "2")), dim=1)
         p = self.params
         # hand-written skinny products; dense1's ReLU backward is applied in the output layer's
         # input-gradient store.  (Widths that are not multiples of 4 floats are refused in
