@@ -236,6 +236,21 @@ int    wm_model_train_gather_f32(const float *params, const float *vol, const in
                                  float *loss, float *grads, void *workspace,
                                  size_t workspace_bytes, int64_t B, int64_t B_global, void *stream);
 
+/* Multi-tensor Adam for a whole model: replaces self.optimizer.apply_gradients(...) of the Conv3D
+ * model's train_step (convolution.py:54; compile(optimizer="adam"), :185).  `table` is a HOST array
+ * (read during the call; the records travel to the kernel as launch arguments, 16 per launch)
+ * of ntensors records {float *p; const float *g; float *m; float *v; int64 count; int64 first_block}
+ * (48 bytes each): a workgroup takes 1024 consecutive elements of one tensor, first_block is the
+ * running sum of ceil(count / 1024) and total_blocks its end.  `step` is a DEVICE int holding the
+ * number of steps taken so far; the call uses step + 1 in the bias corrections and then advances it,
+ * all on the stream -- so the call can be captured in a HIP graph and replayed.
+ * keras_eps != 0: keras.optimizers.Adam's update (m += (g - m)(1 - b1); v += (g^2 - v)(1 - b2);
+ * var -= m alpha / (sqrt(v) + eps), alpha = lr sqrt(1 - b2^t) / (1 - b1^t)) -- epsilon OUTSIDE the
+ * bias correction, as the reference's optimizer has it; 0: torch.optim.Adam's, as wm_adam_step_f32. */
+int    wm_adam_multi_f32(const void *table, int ntensors, int64_t total_blocks, int *step,
+                         double lr, double beta1, double beta2, double eps, int keras_eps,
+                         void *stream);
+
 /* torch.optim.Adam step with the reference's defaults semantics (newConvolution.py:185,225):
  * no weight decay, no amsgrad; step counts from 1; grads are multiplied by grad_scale first.
  * lr, betas and eps are doubles, as torch holds them: the bias corrections 1 - beta^step and the

@@ -293,3 +293,47 @@ def test_dense_layers_match_float64(M, K, N):
     torch.relu(F.linear(r2[0], r2[1], r2[2])).sum().backward()
     for a, r in zip(l2, r2):
         assert relinf(a.grad.cpu().numpy(), r.grad.numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("keras_eps", [True, False])
+def test_device_adam_matches_float64_restatement_and_torch(keras_eps):
+    """wm_adam_multi_f32 over several tensors (ragged sizes, one above a workgroup's 1024 elements),
+    five steps, against a float64 restatement of keras.optimizers.Adam.update_step (epsilon outside
+    the bias correction; convolution.py:54,185) resp. torch.optim.Adam; the torch form also against
+    torch itself.  The device step counter advances by one per call."""
+    from weather_model_amd import ops
+    torch.manual_seed(5)
+    shapes = [(7,), (33, 31), (1024,), (3, 5, 7, 11), (2049,)]
+    ps = [torch.randn(s, device="cuda").requires_grad_(True) for s in shapes]
+    ref = [p.detach().double().cpu().numpy().copy() for p in ps]
+    m = [np.zeros_like(r) for r in ref]
+    v = [np.zeros_like(r) for r in ref]
+    lr, b1, b2, eps = 1e-2, 0.9, 0.999, 1e-7
+    opt = ops.DeviceAdam(ps, lr=lr, betas=(b1, b2), eps=eps, keras_eps=keras_eps)
+    tps = [p.detach().clone().requires_grad_(True) for p in ps]
+    topt = torch.optim.Adam(tps, lr=lr, betas=(b1, b2), eps=eps)
+    for t in range(1, 6):
+        grads = [torch.randn(s, device="cuda") * (0.1 if t % 2 else 3.0) for s in shapes]
+        for p, q, g in zip(ps, tps, grads):
+            p.grad = g.clone()
+            q.grad = g.clone()
+        opt.step()
+        topt.step()
+        for k, g in enumerate(grads):
+            gd = g.double().cpu().numpy()
+            m[k] += (gd - m[k]) * (1 - b1)
+            v[k] += (gd * gd - v[k]) * (1 - b2)
+            if keras_eps:
+                alpha = lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+                ref[k] -= m[k] * alpha / (np.sqrt(v[k]) + eps)
+            else:
+                ref[k] -= lr / (1 - b1 ** t) * m[k] / (np.sqrt(v[k]) / np.sqrt(1 - b2 ** t) + eps)
+        assert int(opt._step.item()) == t
+    for k, p in enumerate(ps):
+        moved = np.abs(ref[k] - tps[k].detach().double().cpu().numpy()).max() if keras_eps else None
+        err = np.abs(p.detach().double().cpu().numpy() - ref[k]).max()
+        assert err < 2e-6 * max(1.0, np.abs(ref[k]).max()), (k, err)
+        if not keras_eps:
+            assert np.abs((p - tps[k]).detach().cpu().numpy()).max() < 2e-6, k
+        else:
+            assert moved < 1e-3       # the two epsilon placements differ only where sqrt(v) ~ eps

@@ -48,6 +48,7 @@ SIGNATURES = {
     "wm_model_train_gather_f32": (c_int, [vp, vp, vp, c_i64] + [c_int] * 11 + [vp, vp, vp, vp, c_sz,
                                           c_i64, c_i64, vp]),
     "wm_adam_step_f32": (c_int, [vp, vp, vp, vp, c_i64, c_int, c_f64, c_f64, c_f64, c_f64, c_f32, vp]),
+    "wm_adam_multi_f32": (c_int, [vp, c_int, c_i64, vp, c_f64, c_f64, c_f64, c_f64, c_int, vp]),
     "wm_field_stats_workspace_bytes": (c_sz, [c_i64]),
     "wm_field_stats_f32": (c_int, [vp, c_i64, vp, c_int, vp, c_sz, vp]),
     "wm_affine_scale_f32": (c_int, [vp, vp, c_i64, c_f32, c_f32, vp]),

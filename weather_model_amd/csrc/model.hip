@@ -909,6 +909,103 @@ static int model_train_impl(const float *params, const float *x, const float *y,
     return WM_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// Multi-tensor Adam with the step counter on the device (the Conv3D model's optimizer.apply_gradients,
+// convolution.py:54 with compile(optimizer="adam"), :185): one launch updates every parameter tensor
+// of the model, and because the counter is read and advanced on the device the call can sit in a
+// captured HIP graph and be replayed.  A workgroup takes 1024 consecutive elements of one tensor.
+struct AdamTensor {
+    float *p;
+    const float *g;
+    float *m;
+    float *v;
+    long long count;
+    long long first_block;
+};
+
+namespace {
+
+constexpr int ADAM_MAXT = 16;       // records per launch: they travel as kernel arguments (768 bytes)
+struct AdamTable {
+    AdamTensor t[ADAM_MAXT];
+};
+
+__global__ __launch_bounds__(256) void adam_multi_kernel(const AdamTable tabv, int ntab,
+                                                         const int *__restrict__ step, double lr,
+                                                         double beta1, double beta2, float eps,
+                                                         int keras_eps)
+{
+    __shared__ float sc[2];
+    if (threadIdx.x == 0) {
+        const double t = (double)(*step + 1);
+        const double bc1 = 1.0 - pow(beta1, t), bc2 = 1.0 - pow(beta2, t);
+        sc[0] = keras_eps ? (float)(lr * sqrt(bc2) / bc1) : (float)(lr / bc1);
+        sc[1] = (float)sqrt(bc2);
+    }
+    const AdamTensor *tab = tabv.t;
+    int k = 0;
+    while (k + 1 < ntab && tab[k + 1].first_block <= (long long)blockIdx.x) ++k;
+    const AdamTensor t = tab[k];
+    __syncthreads();
+    const float one_minus_b1 = (float)(1.0 - beta1), b2 = (float)beta2, one_minus_b2 = (float)(1.0 - beta2);
+    const long long base = ((long long)blockIdx.x - t.first_block) * 1024;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const long long i = base + u * 256 + threadIdx.x;
+        if (i < t.count) {
+            const float g = t.g[i];
+            float pv = t.p[i], mv = t.m[i], vv = t.v[i];
+            if (keras_eps) {
+                // keras.optimizers.Adam.update_step: m += (g - m)(1 - b1); v += (g^2 - v)(1 - b2);
+                // var -= m * alpha / (sqrt(v) + eps), alpha = lr sqrt(1 - b2^t) / (1 - b1^t)
+                mv = mv + (g - mv) * one_minus_b1;
+                vv = vv + (g * g - vv) * one_minus_b2;
+                pv = pv - (mv * sc[0]) / (sqrtf(vv) + eps);
+            } else {
+                const AdamScalars a{one_minus_b1, b2, one_minus_b2, eps, sc[0], sc[1], 1.0f};
+                adam_update(pv, mv, vv, g, a);
+            }
+            t.p[i] = pv;
+            t.m[i] = mv;
+            t.v[i] = vv;
+        }
+    }
+}
+
+__global__ void adam_step_advance_kernel(int *step) { if (threadIdx.x == 0) *step += 1; }
+
+}  // namespace
+
+extern "C" int wm_adam_multi_f32(const void *table, int ntensors, int64_t total_blocks, int *step,
+                                 double lr, double beta1, double beta2, double eps, int keras_eps,
+                                 void *stream)
+{
+    WM_REQUIRE(table && step && ntensors > 0 && total_blocks > 0 && total_blocks < (1ll << 31),
+               WM_ERR_INVALID, "wm_adam_multi_f32: bad arguments");
+    const AdamTensor *rec = (const AdamTensor *)table;
+    for (int t0 = 0; t0 < ntensors; t0 += ADAM_MAXT) {          // the records go in as kernel arguments
+        const int nt = ntensors - t0 < ADAM_MAXT ? ntensors - t0 : ADAM_MAXT;
+        AdamTable tv = {};
+        const long long b0 = rec[t0].first_block;
+        for (int k = 0; k < nt; ++k) {
+            WM_REQUIRE(rec[t0 + k].p && rec[t0 + k].g && rec[t0 + k].m && rec[t0 + k].v &&
+                           rec[t0 + k].count > 0, WM_ERR_INVALID,
+                       "wm_adam_multi_f32: record %d has a null pointer or no elements", t0 + k);
+            tv.t[k] = rec[t0 + k];
+            tv.t[k].first_block -= b0;
+        }
+        const long long b1 = t0 + nt < ntensors ? rec[t0 + nt].first_block : (long long)total_blocks;
+        WM_REQUIRE(b1 > b0, WM_ERR_INVALID, "wm_adam_multi_f32: first_block must increase");
+        hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)(b1 - b0)), dim3(256), 0,
+                           (hipStream_t)stream, tv, nt, (const int *)step, lr, beta1, beta2, (float)eps,
+                           keras_eps);
+        WM_LAUNCH_CHECK("adam_multi_kernel");
+    }
+    hipLaunchKernelGGL(adam_step_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step);
+    WM_LAUNCH_CHECK("adam_step_advance_kernel");
+    return WM_OK;
+}
+
 extern "C" int wm_adam_step_f32(float *params, const float *grads, float *m, float *v,
                                 int64_t count, int step, double lr, double beta1, double beta2,
                                 double eps, float grad_scale, void *stream)

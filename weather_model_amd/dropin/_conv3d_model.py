@@ -175,8 +175,8 @@ class Conv3DModel:
         if optimizer not in ("adam", "Adam") and not isinstance(optimizer, torch.optim.Optimizer):
             raise ValueError("optimizer must be 'adam' or a torch optimizer over model.params")
         self.optimizer = optimizer if isinstance(optimizer, torch.optim.Optimizer) else \
-            torch.optim.Adam(list(self.params.values()), lr=1e-3, betas=(0.9, 0.999), eps=1e-7,
-                             capturable=True, fused=True)     # one multi-tensor kernel, not ten
+            ops.DeviceAdam(list(self.params.values()), lr=1e-3, betas=(0.9, 0.999), eps=1e-7,
+                           keras_eps=True)     # one launch for all tensors, Keras' epsilon placement
         keys = []
         for m in list(metrics or []) + list(weighted_metrics or []):
             m = {"mean_absolute_error": "mae", "mean_squared_logarithmic_error": "msle"}.get(m, m)

@@ -14,6 +14,8 @@ from __future__ import annotations
 import ctypes
 import math
 
+import numpy as np
+
 import torch
 
 from . import _lib
@@ -875,6 +877,62 @@ def adam_step(params, grads, m, v, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e
                                                v.data_ptr(), params.numel(), int(step), float(lr),
                                                float(beta1), float(beta2), float(eps),
                                                float(grad_scale), _stream()))
+
+
+class DeviceAdam(torch.optim.Optimizer):
+    """Adam over a list of parameter tensors in ONE launch (wm_adam_multi_f32), step counter on the
+    device -- capturable in a HIP graph.  ``keras_eps=True`` is keras.optimizers.Adam's update
+    (epsilon outside the bias correction: what the reference's Conv3D model trains with,
+    convolution.py:54,185); False is torch.optim.Adam's.  State per parameter: ``exp_avg``,
+    ``exp_avg_sq`` and the shared device counter ``step``."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-7, keras_eps=True):
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps))
+        self.keras_eps = bool(keras_eps)
+        self._step = None
+        self._tables = {}
+
+    def _params(self):
+        return [p for grp in self.param_groups for p in grp["params"]]
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        ps = [p for p in self._params() if p.grad is not None]
+        if not ps:
+            return None
+        dev = ps[0].device
+        if self._step is None:
+            self._step = torch.zeros((), dtype=torch.int32, device=dev)
+        for p in ps:
+            st = self.state[p]
+            if not st:
+                st["step"] = self._step
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            for name, t in (("param", p), ("grad", p.grad)):
+                if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+                    raise TypeError(f"DeviceAdam: {name} must be a contiguous float32 CUDA tensor")
+        key = tuple((p.data_ptr(), p.grad.data_ptr(), self.state[p]["exp_avg"].data_ptr(),
+                     self.state[p]["exp_avg_sq"].data_ptr(), p.numel()) for p in ps)
+        ent = self._tables.get(key)
+        if ent is None:
+            rec = np.zeros((len(ps), 6), dtype=np.int64)
+            blocks = 0
+            for k, row in enumerate(key):
+                rec[k, :5] = row
+                rec[k, 5] = blocks
+                blocks += (row[4] + 1023) // 1024
+            ent = self._tables[key] = (rec, blocks)       # host records: they go in as launch arguments
+            if len(self._tables) > 64:
+                self._tables = {key: ent}
+        table, nblocks = ent
+        grp = self.param_groups[0]
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().wm_adam_multi_f32(
+                table.ctypes.data, len(ps), nblocks, self._step.data_ptr(), float(grp["lr"]),
+                float(grp["betas"][0]), float(grp["betas"][1]), float(grp["eps"]),
+                1 if self.keras_eps else 0, _stream()))
+        return None
 
 
 class ModelFunction(torch.autograd.Function):
