@@ -246,6 +246,9 @@ SYRK_SHAPES = [
     # F, P: one tile (4-way k split); two tiles; three tiles in one superblock; two superblocks
     # with a ragged last block; scalar fill (P % 4 != 0, F % 4 != 0); the reference's shape
     (24, 8), (60, 4), (100, 12), (130, 2), (33, 7), (200, 56), (432, 216),
+    # F % 4 == 0 with ANY P: X by LDS-direct loads, the P + 1 columns of Y and of the ones by hand
+    # (P = 1, 2, 6; Y and the ones column in the second superblock; Y straddling two superblocks)
+    (32, 1), (16, 2), (12, 6), (128, 3), (124, 9),
 ]
 
 
@@ -302,8 +305,9 @@ def test_blocked_solve_matches_float64_oracle(F, P):
     assert np.isfinite(ops.normal_solve(accc, F, P, ridge=1e-3).cpu().numpy()).all()
 
 
-@pytest.mark.parametrize("F,P", [(24, 8), (100, 12), (200, 56), (432, 216)],
-                         ids=["one_pair", "diag_superblock", "six_pairs", "reference_shape"])
+@pytest.mark.parametrize("F,P", [(24, 8), (100, 12), (200, 56), (432, 216), (32, 1), (124, 9)],
+                         ids=["one_pair", "diag_superblock", "six_pairs", "reference_shape", "p1_by_hand",
+                              "y_straddles"])
 def test_gram_syrk_balanced_schedule_large_n(F, P):
     """Row counts large enough for the balanced persistent schedule (mode 1 of gram_syrk.hip):
     exact on integers (any slip in the stage dealing or the slab map loses or doubles rows), and

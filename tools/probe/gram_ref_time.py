@@ -24,7 +24,9 @@ def timeit(fn, reps=10, rounds=5):
 
 shapes = [(2, 1, 400_000_000), (1, 1, 400_000_000), (4, 2, 200_000_000), (8, 4, 100_000_000), (10, 5, 80_000_000),
           (432, 216, 1_000_000), (64, 8, 8_000_000), (128, 64, 4_000_000)]
-if len(sys.argv) > 1:
+if len(sys.argv) > 1 and ":" in sys.argv[1]:           # F:P:n triples
+    shapes = [tuple(int(v) for v in a.split(":")) for a in sys.argv[1:]]
+elif len(sys.argv) > 1:
     shapes = [s for s in shapes if str(s[0]) in sys.argv[1:]]
 for F, P, n in shapes:
     X = ops.synth_uniform((n, F), seed=1); Y = ops.synth_uniform((n, P), seed=2)

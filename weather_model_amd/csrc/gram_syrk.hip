@@ -170,6 +170,7 @@ struct SyPlan {
     int NB64, NSB, npairs, mode;
     int S;                      // mode 0: slices
     int slots, used;            // mode 1: workgroup slots per group, slots in use
+    int yslow;                  // FAST kernels: Y rows are not 16-byte pieces -- its columns are filled by hand
     short w[SY_MAXP], off[SY_MAXP + 1];
 };
 
@@ -218,7 +219,7 @@ __device__ __forceinline__ SyWork sy_assign(const SyPlan &pl, int bid, int half,
 // FAST: rows are 16-byte aligned and n is a multiple of SY_ROWS (LDS-direct fill); otherwise a
 // scalar fill that takes any shape and zero-fills the rows past n.
 // HALVES: 1 = mode 0 (four waves), 2 = mode 1 (eight waves, two stages in flight).
-template <bool FAST, int HALVES>
+template <bool FAST, int HALVES, bool YSLOW = false>
 __global__ __launch_bounds__(BLOCK * HALVES, 2) void gram_syrk_kernel(
     const float *__restrict__ X, const float *__restrict__ Y, long long n, int F, int P,
     const SyPlan pl, const float *__restrict__ consts, double *__restrict__ slabs)
@@ -241,10 +242,21 @@ __global__ __launch_bounds__(BLOCK * HALVES, 2) void gram_syrk_kernel(
     const int lr = lane >> 5, lc = 4 * (lane & 31);
     const float *src[2];
     long long sstride[2], sskip[2];
+    bool dma[2] = {true, true};
     if (FAST) {
+        // Y with P % 4 != 0 (P = 1 above all) has no 16-byte pieces to hand to the LDS-direct loads:
+        // then only the X columns come by DMA (lanes on other columns sit the instruction out), the
+        // padding columns are zeroed once here, and every fill writes the P + 1 columns of Y and of
+        // the ones by hand.  (Before round 3 such shapes took the scalar-fill kernel for EVERYTHING:
+        // F = 32, P = 1 at 0.3 TB/s.)
+        if (YSLOW) {
+            for (int e = tid * 4; e < 2 * SY_PANEL; e += BLOCK * 4) wm_store4(smem + e, (f32x4){0.f, 0.f, 0.f, 0.f});
+            __syncthreads();
+        }
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const int v = (p == 0 ? I : J) * SY_PC + lc;
+            dma[p] = !(YSLOW && v >= F);
             if (v < F) { src[p] = X + v; sstride[p] = F; }
             else if (v < M) { src[p] = Y + (v - F); sstride[p] = P; }
             else if (v == M) { src[p] = consts; sstride[p] = 0; }
@@ -281,10 +293,23 @@ __global__ __launch_bounds__(BLOCK * HALVES, 2) void gram_syrk_kernel(
                 if (p == 1 && !two_panels) break;
 #pragma unroll
                 for (int m = 0; m < SY_ROWS / 2 / WAVES; ++m) {
-                    WM_GLDS16(src[p], smem + p * SY_PANEL + 2 * (wv + WAVES * m) * SY_PC);
+                    if (!YSLOW || dma[p]) WM_GLDS16(src[p], smem + p * SY_PANEL + 2 * (wv + WAVES * m) * SY_PC);
                     src[p] += sstride[p];
                 }
                 src[p] += sskip[p];
+            }
+            if (YSLOW) {
+                const long long row0 = t_load * SY_ROWS;
+                for (int p = 0; p < (two_panels ? 2 : 1); ++p) {
+                    const int vb = (p == 0 ? I : J) * SY_PC;
+                    const int c0 = F > vb ? F : vb, c1 = M < vb + SY_PC - 1 ? M : vb + SY_PC - 1;
+                    const int nc = c1 - c0 + 1;
+                    for (int e = tid; e < SY_ROWS * nc; e += BLOCK) {
+                        const int r = e / nc, c = c0 + e - r * nc;
+                        smem[p * SY_PANEL + r * SY_PC + (c - vb)] =
+                            c < M ? Y[(row0 + r) * P + (c - F)] : 1.0f;
+                    }
+                }
             }
         } else {
             const long long row0 = t_load * SY_ROWS;
@@ -491,7 +516,7 @@ SyPlan sy_plan(long long n, int F, int P, bool fast)
 
 int sy_lds_once(const void *fn, size_t bytes, int slot)
 {
-    static bool done[64][3] = {};
+    static bool done[64][5] = {};
     int dev = 0;
     WM_HIP(hipGetDevice(&dev));
     bool &d = done[dev & 63][slot];
@@ -526,8 +551,8 @@ int wm_gram_syrk_launch(const float *X, const float *Y, long long n, int F, int 
 {
     float *consts = (float *)workspace;
     double *slabs = (double *)((char *)workspace + SY_CONST_BYTES);
-    const bool fast = F % 4 == 0 && P % 4 == 0 && (((uintptr_t)X) & 15) == 0 &&
-                      (((uintptr_t)Y) & 15) == 0;
+    const bool fast = F % 4 == 0 && (((uintptr_t)X) & 15) == 0;
+    const bool yslow = P % 4 != 0 || (((uintptr_t)Y) & 15) != 0;
     // aligned shapes: whole stages through the LDS-direct kernel, the last n % 64 rows through the
     // scalar-fill kernel (a second pass over the same slabs, stream-ordered)
     const long long n_fast = fast ? n - n % SY_ROWS : 0;
@@ -536,23 +561,28 @@ int wm_gram_syrk_launch(const float *X, const float *Y, long long n, int F, int 
         if (rows == 0) continue;
         const float *Xp = pass == 0 ? X : X + n_fast * F;
         const float *Yp = pass == 0 ? Y : Y + n_fast * P;
-        const SyPlan p = sy_plan(rows, F, P, pass == 0);
+        SyPlan p = sy_plan(rows, F, P, pass == 0);
+        p.yslow = pass == 0 && yslow;
         const int grid = (int)sy_plan_wgs(p);
         const size_t lds = 2 * SY_PANEL * sizeof(float);
         if (pass == 0) {
             hipLaunchKernelGGL(gram_syrk_consts_kernel, dim3(1), dim3(64), 0, st, consts);
             WM_LAUNCH_CHECK("gram_syrk_consts_kernel");
+#define SY_LAUNCH_FAST(HALVES_, YSLOW_, SLOT_)                                                    \
+    {                                                                                             \
+        int rc = sy_lds_once((const void *)gram_syrk_kernel<true, HALVES_, YSLOW_>, HALVES_ * lds, \
+                             SLOT_);                                                              \
+        if (rc != WM_OK) return rc;                                                               \
+        hipLaunchKernelGGL((gram_syrk_kernel<true, HALVES_, YSLOW_>), dim3(grid),                 \
+                           dim3(HALVES_ * BLOCK), HALVES_ * lds, st, Xp, Yp, rows, F, P, p,       \
+                           (const float *)consts, slabs);                                         \
+    }
             if (p.mode == 1) {
-                int rc = sy_lds_once((const void *)gram_syrk_kernel<true, 2>, 2 * lds, 0);
-                if (rc != WM_OK) return rc;
-                hipLaunchKernelGGL((gram_syrk_kernel<true, 2>), dim3(grid), dim3(2 * BLOCK), 2 * lds,
-                                   st, Xp, Yp, rows, F, P, p, (const float *)consts, slabs);
+                if (yslow) SY_LAUNCH_FAST(2, true, 3) else SY_LAUNCH_FAST(2, false, 0)
             } else {
-                int rc = sy_lds_once((const void *)gram_syrk_kernel<true, 1>, lds, 1);
-                if (rc != WM_OK) return rc;
-                hipLaunchKernelGGL((gram_syrk_kernel<true, 1>), dim3(grid), dim3(BLOCK), lds, st, Xp,
-                                   Yp, rows, F, P, p, (const float *)consts, slabs);
+                if (yslow) SY_LAUNCH_FAST(1, true, 4) else SY_LAUNCH_FAST(1, false, 1)
             }
+#undef SY_LAUNCH_FAST
         } else {
             int rc = sy_lds_once((const void *)gram_syrk_kernel<false, 1>, lds, 2);
             if (rc != WM_OK) return rc;
