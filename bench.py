@@ -348,7 +348,9 @@ def gram_kernel_name(F, P):
         return "gram_f16_kernel"
     if (F, P) == (64, 1):
         return "gram_x64_kernel"
-    return "gram_small_kernel" if F + P <= 15 else "gram_syrk_kernel"
+    if F + P <= 15:
+        return "gram_small_kernel"
+    return "gram_mid_kernel" if F + P + 1 <= 64 else "gram_syrk_kernel"
 
 
 def run_gram(F, n_rows, steps, warmup, rank, world, cpu_base, P=1, dist="uniform"):
@@ -1254,7 +1256,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="all", choices=["all", "gram16", "conv3x3", "gram64", "model32", "fields", "conv32", "conv32x3",
-                             "conv3d_model", "plumbing", "gram_ref_multi", "gram_ref_single",
+                             "conv3d_model", "plumbing", "gram_ref_multi", "gram_ref_single", "gram_mid",
                              "gram16_normal"])
     ap.add_argument("--rows", type=int, default=100_000_000, help="rows per GPU (gram16)")
     ap.add_argument("--rows64", type=int, default=1_250_000_000,
@@ -1325,6 +1327,9 @@ def main():
             "gram_ref_single": (432, 216, 1_000_000, "uniform",
                                 "singleRegression's own fit (6^3 cubes of T: "
                                 "singleRegression.py:21,33,74-85)"),
+            "gram_mid": (16, 8, 100_000_000, "uniform",
+                         "multipleRegression's fit with eight variables at CUBE_SIZE 1 (F = 2p, P = p, "
+                         "p = 8: multipleRegression.py:273-286)"),
             "gram16_normal": (16, 1, args.rows, "normal",
                               "multipleRegression least squares on standardised features "
                               "(multipleRegression.py:195-197)")}.items():

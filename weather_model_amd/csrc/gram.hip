@@ -452,6 +452,16 @@ int f16_grid()
 
 }  // namespace
 
+// where gram_mid_kernel (register-fed, any alignment) beats the LDS-staged SYRK: see DESIGN.md
+static bool mid_preferred(int F, int P)
+{
+#ifdef WM_PROBE_ENV
+    if (const char *e = getenv("WM_GRAM_MID")) return atoi(e) != 0;
+#endif
+    (void)F; (void)P;
+    return true;
+}
+
 extern "C" size_t wm_gram_workspace_bytes(int64_t n, int F, int P)
 {
     if (n <= 0 || F <= 0 || P <= 0 || wm_num_cus() <= 0) return 0;
@@ -467,6 +477,8 @@ extern "C" size_t wm_gram_workspace_bytes(int64_t n, int F, int P)
     }
     const size_t bs = wm_gram_small_workspace_bytes(F, P);
     if (bs > b) b = bs;
+    const size_t bm = wm_gram_mid_workspace_bytes(F, P);
+    if (bm > b) b = bm;
     return wm_align_up(b, 256);
 }
 
@@ -505,6 +517,8 @@ extern "C" int wm_gram_f32(const float *X, const float *Y, int64_t n, int F, int
     }
     if (wm_gram_small_supported(X, Y, F, P))
         return wm_gram_small_launch(X, Y, (long long)n, F, P, acc, partial, st);
+    if (wm_gram_mid_supported(F, P) && mid_preferred(F, P))
+        return wm_gram_mid_launch(X, Y, (long long)n, F, P, acc, partial, st);
     return wm_gram_syrk_launch(X, Y, (long long)n, F, P, acc, workspace, st);
 }
 

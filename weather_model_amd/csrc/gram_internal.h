@@ -2,6 +2,8 @@
 //   gram.hip        F = 16 / F = 64 with P = 1 (BASELINE configs 2 and 5), the solve, predict
 //   gram_small.hip  F + P <= 15 on the VALU, HBM-bound streaming (the reference's own
 //                   multipleRegression shape F = 2, P = 1: multipleRegression.py:35,273-286)
+//   gram_mid.hip    F + P + 1 <= 64 otherwise: operands straight from global memory into MFMA
+//                   registers, any alignment (the drop-ins' multi-variable fits, F = 2p, P = p)
 //   gram_syrk.hip   every other shape: LDS-staged blocked Z'Z on fp32 MFMA (the reference's
 //                   singleRegression shape F = 432, P = 216: singleRegression.py:21,33,74-85)
 #pragma once
@@ -19,3 +21,9 @@ int wm_gram_small_launch(const float *X, const float *Y, long long n, int F, int
 size_t wm_gram_syrk_workspace_bytes(long long n, int F, int P);
 int wm_gram_syrk_launch(const float *X, const float *Y, long long n, int F, int P, double *acc,
                         void *workspace, hipStream_t st);
+
+// F + P + 1 <= 64, any alignment.  Workspace: per-wave float64 slabs.
+bool wm_gram_mid_supported(int F, int P);
+size_t wm_gram_mid_workspace_bytes(int F, int P);
+int wm_gram_mid_launch(const float *X, const float *Y, long long n, int F, int P, double *acc,
+                       double *slabs, hipStream_t st);
