@@ -323,3 +323,32 @@ def test_gram_syrk_balanced_schedule_large_n(F, P):
     assert torch.equal(ops.gram(Xd, Yd), a)
     X, Y, _ = synth.regression_problem(n, F, P, seed=400 + F, dist="uniform")
     assert relinf(ops.gram(_dev(X), _dev(Y)).cpu().numpy(), ocpu.gram(X, Y)) < 2e-6
+
+
+@pytest.mark.parametrize("F,P", [(16, 8), (12, 6), (14, 7), (24, 12), (40, 20), (33, 7), (62, 1), (15, 1)],
+                         ids=lambda v: str(v))
+def test_gram_mid_kernel_alignments_and_tails(F, P):
+    """gram_mid.hip (15 < F + P, F + P + 1 <= 64): vector-load and dword-load variants, both column
+    widths (D <= 32, D <= 64), pointers moved off their 16- / 8-byte alignment, row counts around the
+    k-step (4 rows), the in-flight batch and the per-wave ranges; exact on integers, and against the
+    float64 oracle on random rows."""
+    from weather_model_amd import ops, synth
+    from oracle import cpu as ocpu
+    for n in (1, 3, 4, 5, 63, 64, 65, 8191, 8192 * 4 + 3, 300_007):
+        X, Y = _int_problem(n, F, P)
+        ref = ocpu.gram(X, Y)
+        a = ops.gram(_dev(X), _dev(Y)).cpu().numpy()
+        assert np.array_equal(a, ref), (F, P, n, np.argwhere(a != ref)[:4])
+        for off in (1, 2):                        # 4- and 8-byte offsets from the allocation
+            bx = torch.zeros(n * F + off, device="cuda")
+            by = torch.zeros(n * P + off, device="cuda")
+            bx[off:] = _dev(X).reshape(-1)
+            by[off:] = _dev(Y).reshape(-1)
+            b = ops.gram(bx[off:].view(n, F), by[off:].view(n, P)).cpu().numpy()
+            assert np.array_equal(b, ref), (F, P, n, off)
+    n = 200_000
+    X, Y, _ = synth.regression_problem(n, F, P, seed=700 + F, dist="normal")
+    Xd, Yd = _dev(X), _dev(Y)
+    a = ops.gram(Xd, Yd)
+    assert relinf(a.cpu().numpy(), ocpu.gram(X, Y)) < 2e-6
+    assert torch.equal(ops.gram(Xd, Yd), a)                       # bitwise reproducible
