@@ -358,6 +358,29 @@ int wm_mse_metrics_f32(const float *pred, const float *y, int B, int64_t P, int 
                        float eps, float *grad, float *out3, void *workspace,
                        size_t workspace_bytes, void *stream);
 
+/* What model.fit / model.evaluate report per epoch for the linear stacks -- the loss (mean squared
+ * error) and the compiled metrics mae / msle of the CURRENT coefficients over the rows
+ * (multipleRegression.py:292-296: compile(loss=mean_squared_error, weighted_metrics=['mae','msle']);
+ * singleRegression.py:90-94; evaluated by fit, :341-350 / :500-509) -- as one streaming pass over X
+ * and Y: pred = [X | 1] beta is formed in registers (float64 accumulation as in
+ * wm_linear_predict_f32, rounded to float32 like the model's output) and never written.
+ *   sums[0] += sum (pred - y)^2      sums[1] += sum |pred - y|
+ *   sums[2] += sum (log1p(max(pred, eps)) - log1p(max(y, eps)))^2   (only when want_msle != 0)
+ *   sums[3] += n * P
+ * sums is a float64[4] on the device; per-workgroup float64 partials go through `workspace` and are
+ * combined in a fixed order.  wm_linear_metrics_f32 takes (F + 1) * P' <= 4096 (P' = P rounded up to one of 1, 2, 4, 6, 8, 16,
+ * 32) and P <= 32
+ * (wm_linear_metrics_supported; WM_ERR_UNSUPPORTED beyond: form the predictions with a GEMM and call
+ * wm_residual_sums_f32 on them, count = n * P). */
+size_t wm_linear_metrics_workspace_bytes(void);
+int wm_linear_metrics_supported(int F, int P);
+int wm_linear_metrics_f32(const float *X, const float *Y, const double *beta, int64_t n, int F,
+                          int P, int want_msle, float msle_eps, double *sums, void *workspace,
+                          size_t workspace_bytes, void *stream);
+int wm_residual_sums_f32(const float *pred, const float *Y, int64_t count, int want_msle,
+                         float msle_eps, double *sums, void *workspace, size_t workspace_bytes,
+                         void *stream);
+
 /* ------------------------------------------------------------------ exchange step ------- */
 
 /* The one collective of the data-parallel path (SURVEY.md 8b ABI block, 8e) for hosts without

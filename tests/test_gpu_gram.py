@@ -352,3 +352,57 @@ def test_gram_mid_kernel_alignments_and_tails(F, P):
     a = ops.gram(Xd, Yd)
     assert relinf(a.cpu().numpy(), ocpu.gram(X, Y)) < 2e-6
     assert torch.equal(ops.gram(Xd, Yd), a)                       # bitwise reproducible
+
+
+@pytest.mark.parametrize("shape", [
+    (2, 1, 100_003, True), (16, 8, 70_001, True), (12, 6, 33_333, True), (32, 1, 50_000, False),
+    (16, 8, 40_000, False), (3, 2, 999, True), (64, 32, 20_011, True), (5, 20, 9_000, True),
+    (24, 12, 25_037, True), (8, 4, 64 * 300, True), (40, 16, 12_345, True), (16, 8, 63, True),
+    (256, 2, 5_001, True), (4, 4, 77_777, True),
+    (432, 216, 3_000, True),          # beyond the fused kernel: library GEMM + wm_residual_sums_f32
+])
+def test_linear_metrics_match_float64_restatement(shape):
+    """loss / mae / msle of the current coefficients (multipleRegression.py:292-296) in one fused pass
+    against a float64 numpy restatement; float32 prediction rounding bounds the difference."""
+    from weather_model_amd import ops
+    F, P, n, msle = shape
+    rng = np.random.default_rng(F * 100 + P)
+    X = rng.uniform(0.0, 1.0, (n, F)).astype(np.float32)
+    beta = rng.uniform(-0.5, 0.5, (F + 1, P))
+    Y = (X.astype(np.float64) @ beta[:F] + beta[F] + rng.normal(0, 0.05, (n, P))).astype(np.float32)
+    Xd = torch.from_numpy(X).cuda()
+    sums = ops.linear_metrics(Xd, torch.from_numpy(Y).cuda(), torch.from_numpy(beta).cuda(),
+                              want_msle=msle)
+    pred = (X.astype(np.float64) @ beta[:F] + beta[F]).astype(np.float32).astype(np.float64)
+    d = pred - Y
+    eps = np.float32(1e-7)
+    e = np.log1p(np.maximum(pred, eps)) - np.log1p(np.maximum(Y.astype(np.float64), eps))
+    want = np.array([(d * d).sum(), np.abs(d).sum(), (e * e).sum() if msle else 0.0, n * P])
+    got = sums.cpu().numpy()
+    tol = 2e-4 if F > 64 else 2e-6        # the GEMM path rounds beta and the products to float32
+    assert got[3] == want[3]
+    np.testing.assert_allclose(got[:3], want[:3], rtol=tol, atol=1e-12)
+    # accumulating: a second call over a sub-range adds to the same sums, misaligned X included
+    again = ops.linear_metrics(Xd[1:n // 2], torch.from_numpy(Y[1:n // 2]).cuda(),
+                               torch.from_numpy(beta).cuda(), sums=sums.clone(), want_msle=msle)
+    d2 = d[1:n // 2]
+    np.testing.assert_allclose(float(again[0]), want[0] + (d2 * d2).sum(), rtol=tol)
+    assert float(again[3]) == want[3] + d2.size
+    # bitwise reproducible
+    b = ops.linear_metrics(Xd, torch.from_numpy(Y).cuda(), torch.from_numpy(beta).cuda(), want_msle=msle)
+    assert torch.equal(b, sums)
+
+
+def test_linear_metrics_rejects_bad_shapes():
+    from weather_model_amd import ops
+    X = torch.zeros((10, 4), device="cuda")
+    with pytest.raises(ValueError):
+        ops.linear_metrics(X, torch.zeros((10, 3), device="cuda"),
+                           torch.zeros((5, 2), device="cuda", dtype=torch.float64))
+    with pytest.raises(ValueError):
+        ops.linear_metrics(X, torch.zeros((10, 2), device="cuda"),
+                           torch.zeros((5, 2), device="cuda", dtype=torch.float64),
+                           sums=torch.zeros(3, device="cuda", dtype=torch.float64))
+    s = ops.linear_metrics(X[:0], torch.zeros((0, 2), device="cuda"),
+                           torch.zeros((5, 2), device="cuda", dtype=torch.float64))
+    assert s.tolist() == [0.0, 0.0, 0.0, 0.0]

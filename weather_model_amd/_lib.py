@@ -41,6 +41,10 @@ SIGNATURES = {
     "wm_normal_solve_workspace_bytes": (c_sz, [c_int, c_int]),
     "wm_normal_solve_f64": (c_int, [vp, c_int, c_int, c_int, c_f64, vp, vp, vp, c_sz, vp]),
     "wm_linear_predict_f32": (c_int, [vp, vp, vp, c_i64, c_int, c_int, vp]),
+    "wm_linear_metrics_workspace_bytes": (c_sz, []),
+    "wm_linear_metrics_supported": (c_int, [c_int, c_int]),
+    "wm_linear_metrics_f32": (c_int, [vp, vp, vp, c_i64, c_int, c_int, c_int, c_f32, vp, vp, c_sz, vp]),
+    "wm_residual_sums_f32": (c_int, [vp, vp, c_i64, c_int, c_f32, vp, vp, c_sz, vp]),
     "wm_model_param_count": (c_int, []),
     "wm_model_fwd_f32": (c_int, [vp, vp, vp, c_i64, vp]),
     "wm_model_workspace_bytes": (c_sz, [c_i64]),

@@ -254,31 +254,24 @@ class LinearStackModel:
         return self._finish_sums(sums, prefix)
 
     def _sums_of(self, X, Y, sums):
-        """Add the residual sums of the current beta over one resident chunk."""
-        pred = ops.linear_predict(X, self.beta).double()
-        yv = Y.double()
-        d = pred - yv
-        sums["loss"] += (d * d).sum()
-        if "mean_squared_error" in sums:
-            sums["mean_squared_error"] += (d * d).sum()
-        if "mae" in sums:
-            sums["mae"] += d.abs().sum()
-        if "msle" in sums:
-            e = torch.log1p(pred.clamp_min(_MSLE_EPS)) - torch.log1p(yv.clamp_min(_MSLE_EPS))
-            sums["msle"] += (e * e).sum()
-        sums["_count"] += float(Y.numel())
+        """Add the residual sums of the current beta over one resident chunk: one fused pass
+        (linmetrics.hip) -- the predictions are never written."""
+        ops.linear_metrics(X, Y, self.beta, sums, want_msle="msle" in self._metric_keys,
+                           msle_eps=_MSLE_EPS)
+
+    _SUM_SLOT = {"loss": 0, "mean_squared_error": 0, "mae": 1, "msle": 2}
 
     def _finish_sums(self, sums, prefix=""):
         keys = ["loss"] + self._metric_keys
-        both = torch.stack([sums[k] for k in keys] + [sums["_count"]])
+        both = sums[[self._SUM_SLOT[k] for k in keys] + [3]]
         if dp.world() > 1:
             dp.allreduce_sum_(both)
         vals = (both[:-1] / both[-1].clamp_min(1.0)).cpu().tolist()
         return {prefix + k: float(v) for k, v in zip(keys, vals)}
 
     def _new_sums(self):
-        keys = ["loss"] + self._metric_keys + ["_count"]
-        return {k: torch.zeros((), device=self.device, dtype=torch.float64) for k in keys}
+        """{sum d^2, sum |d|, sum (log1p diff)^2, count} on the device, float64."""
+        return torch.zeros((4,), device=self.device, dtype=torch.float64)
 
     def _loss_from_gram(self, acc):
         """MSE of the current beta over the rows summarised by ``acc`` (the Gram of [X|1|Y]):

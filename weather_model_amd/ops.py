@@ -523,6 +523,40 @@ def linear_predict(X, beta):
     return out
 
 
+def linear_metrics(X, Y, beta, sums=None, want_msle=True, msle_eps=1e-7):
+    """Add {sum d^2, sum |d|, sum (log1p diff)^2, count} of ``[X | 1] beta - Y`` to the float64[4]
+    ``sums`` (created zeroed when None) in one pass over the rows -- the loss / mae / msle that
+    model.fit reports per epoch (multipleRegression.py:292-296).  Large F x P (beyond
+    wm_linear_metrics_supported) forms the predictions with a library GEMM first."""
+    X = _req(X, "X")
+    beta = _req(beta, "beta", torch.float64)
+    Yv = _req(Y if Y.dim() == 2 else Y[:, None], "Y")
+    n, F = X.shape
+    P = beta.shape[1]
+    if beta.shape[0] != F + 1 or Yv.shape != (n, P):
+        raise ValueError(f"beta must be ({F + 1}, P) and Y ({n}, P); got {tuple(beta.shape)}, "
+                         f"{tuple(Yv.shape)}")
+    if sums is None:
+        sums = torch.zeros((4,), device=X.device, dtype=torch.float64)
+    elif sums.shape != (4,) or sums.dtype != torch.float64 or not sums.is_cuda:
+        raise ValueError("sums must be a CUDA float64 tensor of 4")
+    L = _lib.lib()
+    with torch.cuda.device(X.device):
+        ws = torch.empty((max(L.wm_linear_metrics_workspace_bytes(), 8),), device=X.device,
+                         dtype=torch.uint8)
+        if L.wm_linear_metrics_supported(F, P):
+            _lib.check(L.wm_linear_metrics_f32(X.data_ptr(), Yv.data_ptr(), beta.data_ptr(), n, F, P,
+                                               int(bool(want_msle)), float(msle_eps),
+                                               sums.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
+        else:
+            b32 = beta.float()
+            pred = torch.addmm(b32[F], X, b32[:F])
+            _lib.check(L.wm_residual_sums_f32(pred.data_ptr(), Yv.data_ptr(), n * P,
+                                              int(bool(want_msle)), float(msle_eps),
+                                              sums.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
+    return sums
+
+
 # --------------------------------------------------------------------------- fields
 
 def field_stats(x, out=None):
