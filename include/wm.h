@@ -168,6 +168,26 @@ int wm_maxpool3d_fwd_f32(const float *x, float *y, unsigned char *which,
 int wm_maxpool3d_bwd_f32(const float *gy, const unsigned char *which, float *gx,
                          int B, int A1, int A2, int A3, int C, void *stream);
 
+/* The reference's two conv branches end in the same pool and are concatenated for the Dense layers
+ * (convolution.py:164-174: MaxPool3D on each branch, layers.concatenate, Flatten).  The pair forms
+ * run both branches' pools in ONE launch, and sample b of an output (of a gradient) sits at
+ * y + b * y_batch_stride: with y1 = y0 + per-sample size and a stride of twice that, the pools
+ * write -- and their backward reads -- the concatenated (B, 2 * flat) matrix directly: no
+ * concatenation copy forward, no slice copies backward. */
+int wm_maxpool3d_fwd_pair_f32(const float *x0, const float *x1, float *y0, float *y1,
+                              unsigned char *which0, unsigned char *which1, int B, int A1, int A2,
+                              int A3, int C, int64_t y_batch_stride, void *stream);
+int wm_maxpool3d_bwd_pair_f32(const float *gy0, const float *gy1, const unsigned char *which0,
+                              const unsigned char *which1, float *gx0, float *gx1, int B, int A1,
+                              int A2, int A3, int C, int64_t gy_batch_stride, void *stream);
+
+/* Up to any number of device-to-device copies, 8 per launch: `records` is a HOST array of
+ * {void *dst; const void *src; int64 bytes} (read during the call; the records travel as launch
+ * arguments, so the call is graph-capturable).  Stages a batch (x1, x2, y) into the fixed input
+ * buffers of a captured training step (the host side of convolution.py:46-62's train_step) in one
+ * launch.  No counterpart in the reference: Keras feeds its step through tf.data. */
+int wm_copy_multi(const void *records, int ncopies, void *stream);
+
 /* ------------------------------------------------------------------ least squares ------- */
 
 /* Sufficient statistics of the least-squares problem that the reference's linear Dense stacks
@@ -241,15 +261,19 @@ int    wm_model_train_gather_f32(const float *params, const float *vol, const in
  * (read during the call; the records travel to the kernel as launch arguments, 16 per launch)
  * of ntensors records {float *p; const float *g; float *m; float *v; int64 count; int64 first_block}
  * (48 bytes each): a workgroup takes 1024 consecutive elements of one tensor, first_block is the
- * running sum of ceil(count / 1024) and total_blocks its end.  `step` is a DEVICE int holding the
- * number of steps taken so far; the call uses step + 1 in the bias corrections and then advances it,
- * all on the stream -- so the call can be captured in a HIP graph and replayed.
+ * running sum of ceil(count / 1024) and total_blocks its end.  `step` is a DEVICE int holding the number of
+ * updates made so far.  advance != 0: the call first moves it on by one (a one-thread launch) and
+ * then uses it in the bias corrections -- all on the stream, so the call can be captured in a HIP
+ * graph and replayed.  advance == 0 uses the counter as it stands: for a caller that spreads one
+ * step over several calls (a layer updated from its gradient hook on a side stream while the rest
+ * of the backward pass still runs, the other tensors at the end of the step) -- the first call of
+ * the step advances, the others must be ordered after it on the device.
  * keras_eps != 0: keras.optimizers.Adam's update (m += (g - m)(1 - b1); v += (g^2 - v)(1 - b2);
  * var -= m alpha / (sqrt(v) + eps), alpha = lr sqrt(1 - b2^t) / (1 - b1^t)) -- epsilon OUTSIDE the
  * bias correction, as the reference's optimizer has it; 0: torch.optim.Adam's, as wm_adam_step_f32. */
 int    wm_adam_multi_f32(const void *table, int ntensors, int64_t total_blocks, int *step,
                          double lr, double beta1, double beta2, double eps, int keras_eps,
-                         void *stream);
+                         int advance, void *stream);
 
 /* torch.optim.Adam step with the reference's defaults semantics (newConvolution.py:185,225):
  * no weight decay, no amsgrad; step counts from 1; grads are multiplied by grad_scale first.

@@ -337,3 +337,101 @@ def test_device_adam_matches_float64_restatement_and_torch(keras_eps):
             assert np.abs((p - tps[k]).detach().cpu().numpy()).max() < 2e-6, k
         else:
             assert moved < 1e-3       # the two epsilon placements differ only where sqrt(v) ~ eps
+
+
+def test_device_adam_overlap_from_gradient_hooks_equals_plain_step():
+    """DeviceAdam.overlap: tensors updated from their gradient hooks on a side stream while the
+    backward pass is still running, the rest in step() -- bit for bit the one-launch update, step
+    counter advanced once, eager and replayed from a captured graph."""
+    from weather_model_amd import ops
+    torch.manual_seed(11)
+    shapes = [(640, 96), (96,), (96, 40), (40,)]
+    init = [torch.randn(s, device="cuda") * 0.1 for s in shapes]
+    x = torch.randn((16, 640), device="cuda")
+    y = torch.randn((16, 40), device="cuda")
+
+    def make(early):
+        ps = [t.clone().requires_grad_(True) for t in init]
+        opt = ops.DeviceAdam(ps, lr=1e-2, keras_eps=True)
+        if early:
+            opt.overlap([ps[2], ps[0]])
+        return ps, opt
+
+    def one_step(ps, opt, xx):
+        opt.zero_grad(set_to_none=True)
+        h = torch.relu(xx @ ps[0] + ps[1])
+        loss = ((h @ ps[2] + ps[3] - y) ** 2).mean()
+        loss.backward()
+        opt.step()
+        return loss.detach()
+
+    a, oa = make(False)
+    b, ob = make(True)
+    for t in range(1, 4):
+        la, lb = one_step(a, oa, x), one_step(b, ob, x)
+        assert float(la) == float(lb)
+        for p, q in zip(a, b):
+            assert torch.equal(p, q)
+        assert int(ob._step.item()) == t
+    with pytest.raises(ValueError):
+        ob.overlap([b[1], b[3]])                  # something must stay in step()
+    # the same under graph capture: hooks fire during capture, the side stream joins before step()
+    c, oc = make(True)
+    xs = x.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        one_step(c, oc, xs)
+    torch.cuda.current_stream().wait_stream(side)
+    oc.zero_grad(set_to_none=True)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        one_step(c, oc, xs)
+    graph.replay()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert int(oc._step.item()) == 3            # one warm-up step + two replays
+    for p, q in zip(a, c):
+        assert torch.equal(p, q)
+
+
+@pytest.mark.parametrize("shape", [(16, 64, 3, 3, 10), (3, 4, 6, 5, 7), (2, 2, 2, 2, 1), (5, 9, 8, 4, 14)])
+def test_maxpool_cat_pair_equals_pools_and_concatenation(shape):
+    """ops.maxpool3d_cat (one launch for both branches' pools, written straight into the concatenated
+    matrix; convolution.py:164-174) is bit for bit cat(pool(a), pool(b)) -- values against
+    torch.nn.functional.max_pool3d too -- and so are its input gradients."""
+    from weather_model_amd import ops
+    torch.manual_seed(3)
+    a = torch.randn(shape, device="cuda").requires_grad_(True)
+    b = torch.randn(shape, device="cuda").requires_grad_(True)
+    h = ops.maxpool3d_cat(a, b)
+    a2, b2 = a.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+    ref = torch.cat((ops.maxpool3d(a2, True).flatten(1), ops.maxpool3d(b2, True).flatten(1)), 1)
+    assert torch.equal(h, ref)
+    tp = F.max_pool3d(a.detach().permute(0, 4, 1, 2, 3), 2).permute(0, 2, 3, 4, 1).flatten(1)
+    assert torch.equal(h[:, :h.shape[1] // 2], tp)
+    g = torch.randn_like(h)
+    h.backward(g)
+    ref.backward(g)
+    assert torch.equal(a.grad, a2.grad) and torch.equal(b.grad, b2.grad)
+    assert float(a.grad.abs().sum()) > 0
+
+
+def test_copy_multi_one_launch():
+    from weather_model_amd import ops
+    torch.manual_seed(4)
+    srcs = [torch.randn(16, 1, 20, 20, 20, device="cuda"), torch.randn(7, device="cuda"),
+            torch.arange(1001, device="cuda", dtype=torch.uint8)[1:],          # misaligned bytes
+            torch.randn(3, 5, device="cuda", dtype=torch.float64)]
+    dsts = [torch.zeros_like(t) for t in srcs]
+    ops.copy_multi(dsts, srcs)
+    for d, s in zip(dsts, srcs):
+        assert torch.equal(d, s)
+    many_s = [torch.randn(33 + k, device="cuda") for k in range(11)]          # more than one launch
+    many_d = [torch.empty_like(t) for t in many_s]
+    ops.copy_multi(many_d, many_s)
+    assert all(torch.equal(d, s) for d, s in zip(many_d, many_s))
+    with pytest.raises(ValueError):
+        ops.copy_multi([dsts[0]], [srcs[1]])
+    with pytest.raises(ValueError):
+        ops.copy_multi([torch.zeros(4, 4, device="cuda").t()], [torch.zeros(4, 4, device="cuda")])

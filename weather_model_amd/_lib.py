@@ -36,6 +36,9 @@ SIGNATURES = {
     "wm_conv3d_bwd_wb_f32": (c_int, [vp, vp, vp, vp, vp, c_sz] + [c_int] * 9 + [vp]),
     "wm_maxpool3d_fwd_f32": (c_int, [vp, vp, vp] + [c_int] * 5 + [vp]),
     "wm_maxpool3d_bwd_f32": (c_int, [vp, vp, vp] + [c_int] * 5 + [vp]),
+    "wm_maxpool3d_fwd_pair_f32": (c_int, [vp] * 6 + [c_int] * 5 + [c_i64, vp]),
+    "wm_maxpool3d_bwd_pair_f32": (c_int, [vp] * 6 + [c_int] * 5 + [c_i64, vp]),
+    "wm_copy_multi": (c_int, [vp, c_int, vp]),
     "wm_gram_workspace_bytes": (c_sz, [c_i64, c_int, c_int]),
     "wm_gram_f32": (c_int, [vp, vp, c_i64, c_int, c_int, vp, vp, c_sz, vp]),
     "wm_normal_solve_workspace_bytes": (c_sz, [c_int, c_int]),
@@ -52,7 +55,7 @@ SIGNATURES = {
     "wm_model_train_gather_f32": (c_int, [vp, vp, vp, c_i64] + [c_int] * 11 + [vp, vp, vp, vp, c_sz,
                                           c_i64, c_i64, vp]),
     "wm_adam_step_f32": (c_int, [vp, vp, vp, vp, c_i64, c_int, c_f64, c_f64, c_f64, c_f64, c_f32, vp]),
-    "wm_adam_multi_f32": (c_int, [vp, c_int, c_i64, vp, c_f64, c_f64, c_f64, c_f64, c_int, vp]),
+    "wm_adam_multi_f32": (c_int, [vp, c_int, c_i64, vp, c_f64, c_f64, c_f64, c_f64, c_int, c_int, vp]),
     "wm_field_stats_workspace_bytes": (c_sz, [c_i64]),
     "wm_field_stats_f32": (c_int, [vp, c_i64, vp, c_int, vp, c_sz, vp]),
     "wm_affine_scale_f32": (c_int, [vp, vp, c_i64, c_f32, c_f32, vp]),

@@ -2010,6 +2010,40 @@ __global__ __launch_bounds__(1024) void conv3d_reduce16_kernel(const float *__re
     }
 }
 
+// conv3d_reduce16_kernel with 16-byte reads (nent a multiple of 4, slabs 16-byte aligned): a lane owns
+// four consecutive entries, so a wave reads 1 KiB runs of a slab instead of 256-byte ones -- layer 2
+// of the reference's model (48 slabs x 128 064 entries = 24.6 MB): 17 -> 8 us.  Same summation order
+// per entry as the scalar kernel.
+__global__ __launch_bounds__(1024) void conv3d_reduce16v_kernel(const float *__restrict__ partial,
+                                                                int nparts, int nent, int nw,
+                                                                float *__restrict__ gw,
+                                                                float *__restrict__ gb)
+{
+    __shared__ double part[16][64][4];
+    const int le = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int e = (blockIdx.x * 64 + le) * 4;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (e < nent)
+        for (int p = grp; p < nparts; p += 16) {
+            const f32x4 v = __builtin_nontemporal_load(
+                reinterpret_cast<const f32x4 *>(partial + (size_t)p * nent + e));
+            s0 += (double)v[0]; s1 += (double)v[1]; s2 += (double)v[2]; s3 += (double)v[3];
+        }
+    part[grp][le][0] = s0; part[grp][le][1] = s1; part[grp][le][2] = s2; part[grp][le][3] = s3;
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        const int l2 = threadIdx.x >> 2, j = threadIdx.x & 3;
+        const int ee = (blockIdx.x * 64 + l2) * 4 + j;
+        if (ee < nent) {
+            double t = 0.0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) t += part[q][l2][j];
+            if (ee < nw) gw[ee] = (float)t;
+            else if (gb) gb[ee - nw] = (float)t;
+        }
+    }
+}
+
 // the same sum for many slabs (one per persistent workgroup): 64 entries x 16 slab groups per
 // workgroup, group partials combined through LDS in a fixed order
 __global__ __launch_bounds__(1024) void conv3d_reduce_slabs_kernel(const double *__restrict__ partial,
@@ -2039,55 +2073,78 @@ __global__ __launch_bounds__(1024) void conv3d_reduce_slabs_kernel(const double 
 // ------------------------------------------------------------------------------ max pool
 // x is (B, A1, A2, A3, C) contiguous; window 2, stride 2 over A1..A3 -> (B, A1/2, A2/2, A3/2, C).
 // which[out] = position (0..7, a1-major) of the first maximum of the window.
-__global__ __launch_bounds__(BLOCK) void maxpool3d_fwd_kernel(const float *__restrict__ x,
-                                                              float *__restrict__ y,
-                                                              unsigned char *__restrict__ which,
-                                                              int B, int A1, int A2, int A3, int C,
-                                                              long long total)
+// One launch serves up to two tensors of the same shape (blockIdx.y: the model's two conv branches),
+// and sample b of the output sits at y + b * y_bstride: with y1 = y0 + per-sample size and
+// y_bstride = twice that, the two pools write the concatenated (B, 2 * flat) matrix the Dense layer
+// reads -- no concatenation copy.  Index arithmetic in I = 32 bits whenever the tensors allow it (a
+// 64-bit division by a run-time value is a ~150-instruction routine; five of them per element were
+// most of these kernels' time).
+struct PoolPair {
+    const float *x[2];
+    float *y[2];
+    unsigned char *which[2];
+};
+
+template <typename I>
+__global__ __launch_bounds__(BLOCK) void maxpool3d_fwd_kernel(const PoolPair pp, int A1, int A2, int A3,
+                                                              int C, long long total,
+                                                              long long y_bstride)
 {
-    const int P1 = A1 / 2, P2 = A2 / 2, P3 = A3 / 2;
-    for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < total;
-         i += (long long)gridDim.x * BLOCK) {
-        const int c = (int)(i % C);
-        long long t = i / C;
-        const int p3 = (int)(t % P3); t /= P3;
-        const int p2 = (int)(t % P2); t /= P2;
-        const int p1 = (int)(t % P1);
-        const long long b_ = t / P1;
+    const float *__restrict__ x = pp.x[blockIdx.y];
+    float *__restrict__ y = pp.y[blockIdx.y];
+    unsigned char *__restrict__ which = pp.which[blockIdx.y];
+    const I P1 = A1 / 2, P2 = A2 / 2, P3 = A3 / 2;
+    const I per = P1 * P2 * P3 * (I)C;
+    for (I i = (I)blockIdx.x * BLOCK + threadIdx.x; i < (I)total; i += (I)gridDim.x * BLOCK) {
+        const I c = i % (I)C;
+        I t = i / (I)C;
+        const I p3 = t % P3; t /= P3;
+        const I p2 = t % P2; t /= P2;
+        const I p1 = t % P1;
+        const I b_ = t / P1;
+        const float *xb = x + ((((long long)b_ * A1 + 2 * p1) * A2 + 2 * p2) * A3 + 2 * p3) * C + c;
         float best = 0.0f;
         int arg = 0;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const int a1 = 2 * p1 + (q >> 2), a2 = 2 * p2 + ((q >> 1) & 1), a3 = 2 * p3 + (q & 1);
-            const float v = x[(((b_ * A1 + a1) * A2 + a2) * A3 + a3) * C + c];
+            const float v = xb[(((q >> 2) * A2 + ((q >> 1) & 1)) * A3 + (q & 1)) * C];
             if (q == 0 || v > best) { best = v; arg = q; }
         }
-        y[i] = best;
+        y[(long long)b_ * y_bstride + (i - b_ * per)] = best;
         if (which) which[i] = (unsigned char)arg;
     }
 }
 
+struct PoolPairBwd {
+    const float *gy[2];
+    const unsigned char *which[2];
+    float *gx[2];
+};
+
 // one thread per INPUT element: windows do not overlap, so no atomics are needed
-__global__ __launch_bounds__(BLOCK) void maxpool3d_bwd_kernel(const float *__restrict__ gy,
-                                                              const unsigned char *__restrict__ which,
-                                                              float *__restrict__ gx, int B, int A1,
-                                                              int A2, int A3, int C, long long total)
+template <typename I>
+__global__ __launch_bounds__(BLOCK) void maxpool3d_bwd_kernel(const PoolPairBwd pp, int A1, int A2,
+                                                              int A3, int C, long long total,
+                                                              long long gy_bstride)
 {
-    const int P1 = A1 / 2, P2 = A2 / 2, P3 = A3 / 2;
-    for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < total;
-         i += (long long)gridDim.x * BLOCK) {
-        const int c = (int)(i % C);
-        long long t = i / C;
-        const int a3 = (int)(t % A3); t /= A3;
-        const int a2 = (int)(t % A2); t /= A2;
-        const int a1 = (int)(t % A1);
-        const long long b_ = t / A1;
-        const int p1 = a1 >> 1, p2 = a2 >> 1, p3 = a3 >> 1;
+    const float *__restrict__ gy = pp.gy[blockIdx.y];
+    const unsigned char *__restrict__ which = pp.which[blockIdx.y];
+    float *__restrict__ gx = pp.gx[blockIdx.y];
+    const I P1 = A1 / 2, P2 = A2 / 2, P3 = A3 / 2;
+    for (I i = (I)blockIdx.x * BLOCK + threadIdx.x; i < (I)total; i += (I)gridDim.x * BLOCK) {
+        const I c = i % (I)C;
+        I t = i / (I)C;
+        const I a3 = t % (I)A3; t /= (I)A3;
+        const I a2 = t % (I)A2; t /= (I)A2;
+        const I a1 = t % (I)A1;
+        const I b_ = t / (I)A1;
+        const I p1 = a1 >> 1, p2 = a2 >> 1, p3 = a3 >> 1;
         float v = 0.0f;
         if (p1 < P1 && p2 < P2 && p3 < P3) {
-            const long long o = (((b_ * P1 + p1) * P2 + p2) * P3 + p3) * C + c;
-            const int q = ((a1 & 1) << 2) | ((a2 & 1) << 1) | (a3 & 1);
-            if (which[o] == q) v = gy[o];
+            const I within = ((p1 * P2 + p2) * P3 + p3) * (I)C + c;
+            const int q = (int)(((a1 & 1) << 2) | ((a2 & 1) << 1) | (a3 & 1));
+            if (which[b_ * (P1 * P2 * P3 * (I)C) + within] == q)
+                v = gy[(long long)b_ * gy_bstride + within];
         }
         gx[i] = v;
     }
@@ -2596,8 +2653,12 @@ extern "C" int wm_conv3d_bwd_wb_f32(const float *x, const float *gy, float *gw, 
         hipLaunchKernelGGL(wb_vol_kernel(otiles, vktw), dim3(planes, vgroups), dim3(BLOCK), vlds, st,
                            x, gy, (float *)workspace, d, K);
         WM_LAUNCH_CHECK("conv3d_bwd_wb_vol_kernel");
-        hipLaunchKernelGGL(conv3d_reduce16_kernel, dim3((nent + 63) / 64), dim3(1024), 0, st,
-                           (const float *)workspace, planes, nent, nw, gw, gb);
+        if (nent % 4 == 0 && (((uintptr_t)workspace) & 15) == 0)
+            hipLaunchKernelGGL(conv3d_reduce16v_kernel, dim3((nent + 255) / 256), dim3(1024), 0, st,
+                               (const float *)workspace, planes, nent, nw, gw, gb);
+        else
+            hipLaunchKernelGGL(conv3d_reduce16_kernel, dim3((nent + 63) / 64), dim3(1024), 0, st,
+                               (const float *)workspace, planes, nent, nw, gw, gb);
         WM_LAUNCH_CHECK("conv3d_reduce16_kernel");
         return WM_OK;
     }
@@ -2633,36 +2694,96 @@ extern "C" int wm_conv3d_bwd_wb_f32(const float *x, const float *gy, float *gw, 
     return WM_OK;
 }
 
+namespace {
+
+int pool_fwd_launch(const float *x0, const float *x1, float *y0, float *y1, unsigned char *w0,
+                    unsigned char *w1, int B, int A1, int A2, int A3, int C, long long y_bstride,
+                    void *stream, const char *who)
+{
+    WM_REQUIRE(x0 && y0 && (!x1 || y1), WM_ERR_INVALID, "%s: null pointer", who);
+    WM_REQUIRE(B > 0 && A1 >= 2 && A2 >= 2 && A3 >= 2 && C > 0, WM_ERR_INVALID,
+               "%s: pooled axes need at least 2 entries (%d,%d,%d)", who, A1, A2, A3);
+    const long long per = (long long)(A1 / 2) * (A2 / 2) * (A3 / 2) * C;
+    WM_REQUIRE(y_bstride >= per, WM_ERR_INVALID, "%s: output sample stride %lld below the sample size %lld",
+               who, y_bstride, per);
+    const int cus = wm_num_cus();
+    WM_REQUIRE(cus > 0, WM_ERR_NO_DEVICE, "%s: no HIP device", who);
+    const long long total = (long long)B * per;
+    long long blocks = (total + BLOCK - 1) / BLOCK;
+    if (blocks > (long long)cus * 16) blocks = (long long)cus * 16;
+    const PoolPair pp = {{x0, x1}, {y0, y1}, {w0, w1}};
+    const dim3 grid((unsigned)blocks, x1 ? 2 : 1);
+    // 32-bit indices: the input (8 x the output) must stay below 2^31 elements
+    if ((long long)B * A1 * A2 * A3 * C + (long long)cus * 16 * BLOCK < (1ll << 31))
+        hipLaunchKernelGGL(maxpool3d_fwd_kernel<unsigned>, grid, dim3(BLOCK), 0, (hipStream_t)stream, pp,
+                           A1, A2, A3, C, total, y_bstride);
+    else
+        hipLaunchKernelGGL(maxpool3d_fwd_kernel<long long>, grid, dim3(BLOCK), 0, (hipStream_t)stream,
+                           pp, A1, A2, A3, C, total, y_bstride);
+    WM_LAUNCH_CHECK("maxpool3d_fwd_kernel");
+    return WM_OK;
+}
+
+int pool_bwd_launch(const float *gy0, const float *gy1, const unsigned char *w0,
+                    const unsigned char *w1, float *gx0, float *gx1, int B, int A1, int A2, int A3,
+                    int C, long long gy_bstride, void *stream, const char *who)
+{
+    WM_REQUIRE(gy0 && w0 && gx0 && (!gy1 || (w1 && gx1)), WM_ERR_INVALID, "%s: null pointer", who);
+    WM_REQUIRE(B > 0 && A1 >= 2 && A2 >= 2 && A3 >= 2 && C > 0, WM_ERR_INVALID,
+               "%s: pooled axes need at least 2 entries (%d,%d,%d)", who, A1, A2, A3);
+    const long long per = (long long)(A1 / 2) * (A2 / 2) * (A3 / 2) * C;
+    WM_REQUIRE(gy_bstride >= per, WM_ERR_INVALID, "%s: gradient sample stride %lld below the sample size %lld",
+               who, gy_bstride, per);
+    const int cus = wm_num_cus();
+    WM_REQUIRE(cus > 0, WM_ERR_NO_DEVICE, "%s: no HIP device", who);
+    const long long total = (long long)B * A1 * A2 * A3 * C;
+    long long blocks = (total + BLOCK - 1) / BLOCK;
+    if (blocks > (long long)cus * 16) blocks = (long long)cus * 16;
+    const PoolPairBwd pp = {{gy0, gy1}, {w0, w1}, {gx0, gx1}};
+    const dim3 grid((unsigned)blocks, gy1 ? 2 : 1);
+    if (total + (long long)cus * 16 * BLOCK < (1ll << 31))
+        hipLaunchKernelGGL(maxpool3d_bwd_kernel<unsigned>, grid, dim3(BLOCK), 0, (hipStream_t)stream, pp,
+                           A1, A2, A3, C, total, gy_bstride);
+    else
+        hipLaunchKernelGGL(maxpool3d_bwd_kernel<long long>, grid, dim3(BLOCK), 0, (hipStream_t)stream,
+                           pp, A1, A2, A3, C, total, gy_bstride);
+    WM_LAUNCH_CHECK("maxpool3d_bwd_kernel");
+    return WM_OK;
+}
+
+}  // namespace
+
 extern "C" int wm_maxpool3d_fwd_f32(const float *x, float *y, unsigned char *which, int B, int A1,
                                     int A2, int A3, int C, void *stream)
 {
-    WM_REQUIRE(x && y, WM_ERR_INVALID, "wm_maxpool3d_fwd_f32: null pointer");
-    WM_REQUIRE(B > 0 && A1 >= 2 && A2 >= 2 && A3 >= 2 && C > 0, WM_ERR_INVALID,
-               "wm_maxpool3d_fwd_f32: pooled axes need at least 2 entries (%d,%d,%d)", A1, A2, A3);
-    const int cus = wm_num_cus();
-    WM_REQUIRE(cus > 0, WM_ERR_NO_DEVICE, "wm_maxpool3d_fwd_f32: no HIP device");
-    const long long total = (long long)B * (A1 / 2) * (A2 / 2) * (A3 / 2) * C;
-    long long blocks = (total + BLOCK - 1) / BLOCK;
-    if (blocks > (long long)cus * 16) blocks = (long long)cus * 16;
-    hipLaunchKernelGGL(maxpool3d_fwd_kernel, dim3((int)blocks), dim3(BLOCK), 0, (hipStream_t)stream,
-                       x, y, which, B, A1, A2, A3, C, total);
-    WM_LAUNCH_CHECK("maxpool3d_fwd_kernel");
-    return WM_OK;
+    const long long per = (long long)(A1 / 2) * (A2 / 2) * (A3 / 2) * C;
+    return pool_fwd_launch(x, nullptr, y, nullptr, which, nullptr, B, A1, A2, A3, C, per, stream,
+                           "wm_maxpool3d_fwd_f32");
 }
 
 extern "C" int wm_maxpool3d_bwd_f32(const float *gy, const unsigned char *which, float *gx, int B,
                                     int A1, int A2, int A3, int C, void *stream)
 {
-    WM_REQUIRE(gy && which && gx, WM_ERR_INVALID, "wm_maxpool3d_bwd_f32: null pointer");
-    WM_REQUIRE(B > 0 && A1 >= 2 && A2 >= 2 && A3 >= 2 && C > 0, WM_ERR_INVALID,
-               "wm_maxpool3d_bwd_f32: pooled axes need at least 2 entries (%d,%d,%d)", A1, A2, A3);
-    const int cus = wm_num_cus();
-    WM_REQUIRE(cus > 0, WM_ERR_NO_DEVICE, "wm_maxpool3d_bwd_f32: no HIP device");
-    const long long total = (long long)B * A1 * A2 * A3 * C;
-    long long blocks = (total + BLOCK - 1) / BLOCK;
-    if (blocks > (long long)cus * 16) blocks = (long long)cus * 16;
-    hipLaunchKernelGGL(maxpool3d_bwd_kernel, dim3((int)blocks), dim3(BLOCK), 0, (hipStream_t)stream,
-                       gy, which, gx, B, A1, A2, A3, C, total);
-    WM_LAUNCH_CHECK("maxpool3d_bwd_kernel");
-    return WM_OK;
+    const long long per = (long long)(A1 / 2) * (A2 / 2) * (A3 / 2) * C;
+    return pool_bwd_launch(gy, nullptr, which, nullptr, gx, nullptr, B, A1, A2, A3, C, per, stream,
+                           "wm_maxpool3d_bwd_f32");
+}
+
+extern "C" int wm_maxpool3d_fwd_pair_f32(const float *x0, const float *x1, float *y0, float *y1,
+                                         unsigned char *which0, unsigned char *which1, int B, int A1,
+                                         int A2, int A3, int C, int64_t y_batch_stride, void *stream)
+{
+    WM_REQUIRE(x1 && y1, WM_ERR_INVALID, "wm_maxpool3d_fwd_pair_f32: null pointer");
+    return pool_fwd_launch(x0, x1, y0, y1, which0, which1, B, A1, A2, A3, C, (long long)y_batch_stride,
+                           stream, "wm_maxpool3d_fwd_pair_f32");
+}
+
+extern "C" int wm_maxpool3d_bwd_pair_f32(const float *gy0, const float *gy1,
+                                         const unsigned char *which0, const unsigned char *which1,
+                                         float *gx0, float *gx1, int B, int A1, int A2, int A3, int C,
+                                         int64_t gy_batch_stride, void *stream)
+{
+    WM_REQUIRE(gy1 && which1 && gx1, WM_ERR_INVALID, "wm_maxpool3d_bwd_pair_f32: null pointer");
+    return pool_bwd_launch(gy0, gy1, which0, which1, gx0, gx1, B, A1, A2, A3, C,
+                           (long long)gy_batch_stride, stream, "wm_maxpool3d_bwd_pair_f32");
 }

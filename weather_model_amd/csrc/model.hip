@@ -930,6 +930,11 @@ struct AdamTable {
     AdamTensor t[ADAM_MAXT];
 };
 
+// *step = the number of this update (1 for the first): advanced by adam_step_advance_kernel BEFORE the
+// first launch of a step, so that several launches of one step (a layer updated early from its
+// gradient hook, the rest at the end) read the same value and the one-thread launch can sit on a side
+// stream, off the step's critical path.  (A last-workgroup ticket inside this kernel was tried
+// instead of the extra launch: 5600 same-address atomics took the step from 0.41 to 0.60 ms.)
 __global__ __launch_bounds__(256) void adam_multi_kernel(const AdamTable tabv, int ntab,
                                                          const int *__restrict__ step, double lr,
                                                          double beta1, double beta2, float eps,
@@ -937,7 +942,7 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const AdamTable tabv, i
 {
     __shared__ float sc[2];
     if (threadIdx.x == 0) {
-        const double t = (double)(*step + 1);
+        const double t = (double)(*step);
         const double bc1 = 1.0 - pow(beta1, t), bc2 = 1.0 - pow(beta2, t);
         sc[0] = keras_eps ? (float)(lr * sqrt(bc2) / bc1) : (float)(lr / bc1);
         sc[1] = (float)sqrt(bc2);
@@ -978,11 +983,15 @@ __global__ void adam_step_advance_kernel(int *step) { if (threadIdx.x == 0) *ste
 
 extern "C" int wm_adam_multi_f32(const void *table, int ntensors, int64_t total_blocks, int *step,
                                  double lr, double beta1, double beta2, double eps, int keras_eps,
-                                 void *stream)
+                                 int advance, void *stream)
 {
     WM_REQUIRE(table && step && ntensors > 0 && total_blocks > 0 && total_blocks < (1ll << 31),
                WM_ERR_INVALID, "wm_adam_multi_f32: bad arguments");
     const AdamTensor *rec = (const AdamTensor *)table;
+    if (advance) {
+        hipLaunchKernelGGL(adam_step_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step);
+        WM_LAUNCH_CHECK("adam_step_advance_kernel");
+    }
     for (int t0 = 0; t0 < ntensors; t0 += ADAM_MAXT) {          // the records go in as kernel arguments
         const int nt = ntensors - t0 < ADAM_MAXT ? ntensors - t0 : ADAM_MAXT;
         AdamTable tv = {};
@@ -1001,8 +1010,6 @@ extern "C" int wm_adam_multi_f32(const void *table, int ntensors, int64_t total_
                            keras_eps);
         WM_LAUNCH_CHECK("adam_multi_kernel");
     }
-    hipLaunchKernelGGL(adam_step_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step);
-    WM_LAUNCH_CHECK("adam_step_advance_kernel");
     return WM_OK;
 }
 

@@ -111,12 +111,13 @@ class Conv3DModel:
         return (s[0], s[1], s[2] // 2, s[3] // 2, s[4] // 2)
 
     # ------------------------------------------------------------------ forward
-    def _branch(self, x, branch):
+    def _branch(self, x, branch, last_pool=True):
         for li in (1, 2):
             name = f"{branch}Conv3D{li}"
             x = ops.conv3d(x, self.params[name + "/kernel"], self.params[name + "/bias"])
-            x = ops.maxpool3d(x, self.pool_channels_last)
-        return x.reshape(x.shape[0], -1)
+            if li == 1 or last_pool:
+                x = ops.maxpool3d(x, self.pool_channels_last)
+        return x.reshape(x.shape[0], -1) if last_pool else x
 
     # The two conv branches (convolution.py:164-173) are independent until the concatenation and
     # their kernels run 224-workgroup grids on 256 CUs: branch 2 goes to a second stream, forward
@@ -124,8 +125,16 @@ class Conv3DModel:
     # run a kernel of each side by side.  Also under graph capture (the side stream forks from and
     # rejoins the capturing stream through events).
     BRANCH_STREAMS = True
+    # Adam for the two Dense kernels launched from their gradient hooks, beside the conv branches'
+    # backward pass (DeviceAdam.overlap): measured SLOWER here (0.398 -> 0.424 ms per step: the
+    # update is an HBM stream that takes bandwidth from the conv kernels it runs beside), so off.
+    OVERLAP_ADAM = False
+    # the branches' last pools and the concatenation as one launch that writes the Dense layer's
+    # input directly (ops.maxpool3d_cat); needs the channels-last pools the reference runs
+    POOL_CAT = True
 
     def forward(self, x1, x2):
+        fused_cat = self.POOL_CAT and self.pool_channels_last and x1.is_cuda
         if self.BRANCH_STREAMS and x1.is_cuda:
             main = torch.cuda.current_stream(x1.device)
             side = self.__dict__.get("_side_stream")
@@ -133,14 +142,14 @@ class Conv3DModel:
                 side = self._side_stream = torch.cuda.Stream(x1.device)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                h2 = self._branch(x2, "2")
-            h1 = self._branch(x1, "1")
+                h2 = self._branch(x2, "2", not fused_cat)
+            h1 = self._branch(x1, "1", not fused_cat)
             main.wait_stream(side)
             if not torch.cuda.is_current_stream_capturing():
                 h2.record_stream(main)
-            h = torch.cat((h1, h2), dim=1)
         else:
-            h = torch.cat((self._branch(x1, "1"), self._branch(x2, "2")), dim=1)
+            h1, h2 = self._branch(x1, "1", not fused_cat), self._branch(x2, "2", not fused_cat)
+        h = ops.maxpool3d_cat(h1, h2) if fused_cat else torch.cat((h1, h2), dim=1)
         p = self.params
         # hand-written skinny products; dense1's ReLU backward is applied in the output layer's
         # input-gradient store.  (Widths that are not multiples of 4 floats are refused in
@@ -174,9 +183,16 @@ class Conv3DModel:
             raise ValueError(f"only mean_squared_error is implemented (got {name!r})")
         if optimizer not in ("adam", "Adam") and not isinstance(optimizer, torch.optim.Optimizer):
             raise ValueError("optimizer must be 'adam' or a torch optimizer over model.params")
-        self.optimizer = optimizer if isinstance(optimizer, torch.optim.Optimizer) else \
-            ops.DeviceAdam(list(self.params.values()), lr=1e-3, betas=(0.9, 0.999), eps=1e-7,
-                           keras_eps=True)     # one launch for all tensors, Keras' epsilon placement
+        if isinstance(optimizer, torch.optim.Optimizer):
+            self.optimizer = optimizer
+        else:
+            # one launch for all tensors, Keras' epsilon placement; the two Dense kernels (96 % of
+            # the weights, and the first gradients ready) are updated from their gradient hooks on
+            # a side stream while the conv branches' backward pass runs
+            self.optimizer = ops.DeviceAdam(list(self.params.values()), lr=1e-3, betas=(0.9, 0.999),
+                                            eps=1e-7, keras_eps=True)
+            if self.OVERLAP_ADAM:
+                self.optimizer.overlap([self.params["output/kernel"], self.params["dense1/kernel"]])
         keys = []
         for m in list(metrics or []) + list(weighted_metrics or []):
             m = {"mean_absolute_error": "mae", "mean_squared_logarithmic_error": "msle"}.get(m, m)
@@ -328,7 +344,8 @@ class Conv3DModel:
             graphs[key] = g
         for p, gr in zip(self.params.values(), g["grads"]):
             p.grad = gr                                  # an eager step in between may rebind them
-        torch._foreach_copy_([g["x1"], g["x2"], g["y"]], [x1, x2, y])     # one launch, not three
+        ops.copy_multi([g["x1"], g["x2"], g["y"]],                        # one launch, not three
+                       [x1.contiguous(), x2.contiguous(), y.contiguous()])
         g["graph"].replay()
         names = ["loss"] + list(self._metric_keys)
         if not defer:

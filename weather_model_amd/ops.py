@@ -390,6 +390,68 @@ def maxpool3d(input, channels_last=True):
     return MaxPool3dFunction.apply(input, channels_last)
 
 
+class MaxPoolCatFunction(torch.autograd.Function):
+    """``torch.cat((pool(xa).flatten(1), pool(xb).flatten(1)), 1)`` for two tensors of one shape --
+    the end of the reference's two conv branches (convolution.py:164-174) -- as ONE launch that writes
+    the concatenated matrix directly (wm_maxpool3d_fwd_pair_f32); the backward reads the two halves of
+    the incoming gradient in place (wm_maxpool3d_bwd_pair_f32): no concatenation or slice copies."""
+
+    @staticmethod
+    def forward(ctx, xa, xb):
+        xa, xb = _req(xa, "input a"), _req(xb, "input b")
+        if xa.dim() != 5 or xa.shape != xb.shape:
+            raise ValueError(f"maxpool3d_cat expects two 5-D tensors of one shape, got "
+                             f"{tuple(xa.shape)} and {tuple(xb.shape)}")
+        B, A1, A2, A3, C = xa.shape
+        if min(A1, A2, A3) < 2:
+            raise RuntimeError(f"maxpool3d: pooled axes ({A1},{A2},{A3}) are smaller than the window")
+        per = (A1 // 2) * (A2 // 2) * (A3 // 2) * C
+        h = torch.empty((B, 2 * per), device=xa.device, dtype=torch.float32)
+        which = torch.empty((2, B, per), device=xa.device, dtype=torch.uint8)
+        with torch.cuda.device(xa.device):
+            _lib.check(_lib.lib().wm_maxpool3d_fwd_pair_f32(
+                xa.data_ptr(), xb.data_ptr(), h.data_ptr(), h.data_ptr() + 4 * per,
+                which[0].data_ptr(), which[1].data_ptr(), B, A1, A2, A3, C, 2 * per, _stream()))
+        ctx.save_for_backward(which)
+        ctx.x_shape = tuple(xa.shape)
+        return h
+
+    @staticmethod
+    def backward(ctx, gh):
+        (which,) = ctx.saved_tensors
+        B, A1, A2, A3, C = ctx.x_shape
+        per = which.shape[2]
+        gh = _req(gh.contiguous(), "grad_output")
+        gxa = torch.empty(ctx.x_shape, device=gh.device, dtype=torch.float32)
+        gxb = torch.empty(ctx.x_shape, device=gh.device, dtype=torch.float32)
+        with torch.cuda.device(gh.device):
+            _lib.check(_lib.lib().wm_maxpool3d_bwd_pair_f32(
+                gh.data_ptr(), gh.data_ptr() + 4 * per, which[0].data_ptr(), which[1].data_ptr(),
+                gxa.data_ptr(), gxb.data_ptr(), B, A1, A2, A3, C, 2 * per, _stream()))
+        return gxa, gxb
+
+
+def maxpool3d_cat(xa, xb):
+    """(B, 2 * flat): the channels-last 2x2x2 pools of ``xa`` and ``xb``, flattened, side by side."""
+    return MaxPoolCatFunction.apply(xa, xb)
+
+
+def copy_multi(dsts, srcs):
+    """``dst[k].copy_(src[k])`` for contiguous CUDA tensors of equal size and dtype, all in one launch
+    (wm_copy_multi; graph-capturable)."""
+    if len(dsts) != len(srcs) or not dsts:
+        raise ValueError("copy_multi: need as many sources as destinations, at least one")
+    rec = np.zeros((len(dsts), 3), dtype=np.int64)
+    for k, (d, s_) in enumerate(zip(dsts, srcs)):
+        if not (d.is_cuda and s_.is_cuda and d.device == s_.device and d.dtype == s_.dtype and
+                d.shape == s_.shape and d.is_contiguous() and s_.is_contiguous()):
+            raise ValueError(f"copy_multi: pair {k} must be contiguous CUDA tensors of one shape and "
+                             f"dtype on one device")
+        rec[k] = (d.data_ptr(), s_.data_ptr(), d.numel() * d.element_size())
+    with torch.cuda.device(dsts[0].device):
+        _lib.check(_lib.lib().wm_copy_multi(rec.ctypes.data, len(dsts), _stream()))
+
+
 # --------------------------------------------------------------------------- least squares
 
 def gram(X, Y, acc=None):
@@ -918,23 +980,56 @@ class DeviceAdam(torch.optim.Optimizer):
     device -- capturable in a HIP graph.  ``keras_eps=True`` is keras.optimizers.Adam's update
     (epsilon outside the bias correction: what the reference's Conv3D model trains with,
     convolution.py:54,185); False is torch.optim.Adam's.  State per parameter: ``exp_avg``,
-    ``exp_avg_sq`` and the shared device counter ``step``."""
+    ``exp_avg_sq`` and the shared device counter ``step``.
+
+    ``overlap(params)`` moves the update of those tensors out of ``step()`` and into the backward
+    pass: as soon as autograd has accumulated such a tensor's gradient its update is launched on a
+    side stream, beside the rest of the backward pass (the Conv3D model's output layer holds 90 % of
+    the weights and its gradient is the first one ready).  Only for parameters that nothing LATER in
+    the backward pass reads."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-7, keras_eps=True):
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps))
         self.keras_eps = bool(keras_eps)
-        self._step = None
+        self._step = None                  # device int32: updates made (moved on by a step's first launch)
+        self._advanced = False             # this step's first launch has gone out
         self._tables = {}
+        self._early = {}                   # id(param) -> hook handle
+        self._early_done = []
+        self._early_stream = None
 
     def _params(self):
         return [p for grp in self.param_groups for p in grp["params"]]
 
+    def overlap(self, params):
+        params = list(params)
+        mine = {id(p) for p in self._params()}
+        if any(id(p) not in mine for p in params):
+            raise ValueError("DeviceAdam.overlap: not a parameter of this optimizer")
+        if len({id(p) for p in params} | set(self._early)) >= len(mine):
+            raise ValueError("DeviceAdam.overlap: at least one parameter must stay in step()")
+        for p in params:
+            if id(p) not in self._early:
+                self._early[id(p)] = p.register_post_accumulate_grad_hook(self._early_hook)
+
     @torch.no_grad()
-    def step(self, closure=None):
-        ps = [p for p in self._params() if p.grad is not None]
-        if not ps:
-            return None
+    def _early_hook(self, p):
+        if p.grad is None:
+            return
+        main = torch.cuda.current_stream(p.device)
+        side = self._early_stream
+        if side is None or side.device != p.device:
+            side = self._early_stream = torch.cuda.Stream(p.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            self._apply([p])
+        if not torch.cuda.is_current_stream_capturing():
+            p.grad.record_stream(side)
+        self._early_done.append(p)
+
+    def _apply(self, ps):
         dev = ps[0].device
+        advance, self._advanced = not self._advanced, True
         if self._step is None:
             self._step = torch.zeros((), dtype=torch.int32, device=dev)
         for p in ps:
@@ -965,7 +1060,21 @@ class DeviceAdam(torch.optim.Optimizer):
             _lib.check(_lib.lib().wm_adam_multi_f32(
                 table.ctypes.data, len(ps), nblocks, self._step.data_ptr(), float(grp["lr"]),
                 float(grp["betas"][0]), float(grp["betas"][1]), float(grp["eps"]),
-                1 if self.keras_eps else 0, _stream()))
+                1 if self.keras_eps else 0, 1 if advance else 0, _stream()))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        done = {id(p) for p in self._early_done}
+        ps = [p for p in self._params() if p.grad is not None and id(p) not in done]
+        if not ps:
+            if done:
+                raise RuntimeError("DeviceAdam: every gradient of this step went through overlap()")
+            return None
+        if done:                            # the step ends when the early updates have
+            torch.cuda.current_stream(ps[0].device).wait_stream(self._early_stream)
+            self._early_done = []
+        self._apply(ps)
+        self._advanced = False
         return None
 
 
