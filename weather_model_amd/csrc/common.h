@@ -53,6 +53,22 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
 
+// log1p(x) for x >= 0 in ~15 instructions (the library log1pf is ~75 and was most of the loss kernels'
+// time): the odd series 2 atanh(x / (2 + x)) up to x = 1/2 (s <= 1/5: the first omitted term is below
+// 2e-9 of the result), the hardware logarithm of 1 + x beyond, where it is away from its zero.  Within
+// ~2e-7 relative of the float64 value.
+__device__ __forceinline__ float wm_log1p_pos(float x)
+{
+    const float s = x * __builtin_amdgcn_rcpf(2.0f + x);
+    const float s2 = s * s;
+    float poly = fmaf(s2, 1.0f / 9.0f, 1.0f / 7.0f);
+    poly = fmaf(s2, poly, 1.0f / 5.0f);
+    poly = fmaf(s2, poly, 1.0f / 3.0f);
+    poly = fmaf(s2, poly, 1.0f);
+    const float far = __builtin_amdgcn_logf(1.0f + x) * 0.69314718055994530942f;
+    return x <= 0.5f ? 2.0f * s * poly : far;
+}
+
 // 16-byte LDS (or global) accesses through a float pointer.  `*(f32x4 *)(array + i)` is NOT that:
 // clang takes the alignment of such an lvalue from the array's element type (4), and the backend
 // then splits the access into two ds_write2_b32 / ds_read2_b32.

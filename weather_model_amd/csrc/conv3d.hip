@@ -2653,7 +2653,9 @@ extern "C" int wm_conv3d_bwd_wb_f32(const float *x, const float *gy, float *gw, 
         hipLaunchKernelGGL(wb_vol_kernel(otiles, vktw), dim3(planes, vgroups), dim3(BLOCK), vlds, st,
                            x, gy, (float *)workspace, d, K);
         WM_LAUNCH_CHECK("conv3d_bwd_wb_vol_kernel");
-        if (nent % 4 == 0 && (((uintptr_t)workspace) & 15) == 0)
+        // (the 16-byte form needs enough entries to fill the chip with 256-entry workgroups:
+        // layer 1's 11 008 entries x 224 slabs took 9-12 us on 43 of them, 6.9 with the scalar form)
+        if (nent % 4 == 0 && (((uintptr_t)workspace) & 15) == 0 && nent >= 256 * wm_num_cus())
             hipLaunchKernelGGL(conv3d_reduce16v_kernel, dim3((nent + 255) / 256), dim3(1024), 0, st,
                                (const float *)workspace, planes, nent, nw, gw, gb);
         else

@@ -25,6 +25,7 @@ constexpr int JBLOCK = 64;        // float32 pair sums per thread stay this shor
 // with `broadcast`, row i otherwise) -- the p of a wave are consecutive, so every load is
 // coalesced, and B * P threads fill the chip where one thread per column (P = 8000: 125 waves)
 // took 22 us on its serial chain of loads and logs.  partial: [3][gridDim.x] float64.
+template <typename I>
 __global__ __launch_bounds__(BLOCK) void mse_metrics_kernel(const float *__restrict__ pred,
                                                             const float *__restrict__ y, int B,
                                                             long long P, int broadcast, float eps,
@@ -34,11 +35,10 @@ __global__ __launch_bounds__(BLOCK) void mse_metrics_kernel(const float *__restr
     __shared__ double red[BLOCK / 64][3];
     double se = 0.0, ae = 0.0, le = 0.0;
     const long long total = (long long)B * P;
-    for (long long e = (long long)blockIdx.x * BLOCK + threadIdx.x; e < total;
-         e += (long long)gridDim.x * BLOCK) {
-        const long long i = e / P, p = e - i * P;
+    for (I e = (I)blockIdx.x * BLOCK + threadIdx.x; e < (I)total; e += (I)gridDim.x * BLOCK) {
+        const I i = e / (I)P, p = e - i * (I)P;     // (a 64-bit division is a ~150-instruction routine)
         const float pv = pred[e];
-        const float lp = log1pf(fmaxf(pv, eps));
+        const float lp = wm_log1p_pos(fmaxf(pv, eps));
         const int j0 = broadcast ? 0 : (int)i, j1 = broadcast ? B : (int)i + 1;
         double ysum = 0.0;
         for (int jb = j0; jb < j1; jb += JBLOCK) {
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(BLOCK) void mse_metrics_kernel(const float *__restr
 #pragma unroll 8
             for (int j = jb; j < je; ++j) {
                 const float yv = y[(long long)j * P + p];
-                const float d = yv - pv, q = lp - log1pf(fmaxf(yv, eps));
+                const float d = yv - pv, q = lp - wm_log1p_pos(fmaxf(yv, eps));
                 s2 = fmaf(d, d, s2);
                 s1 += fabsf(d);
                 sl = fmaf(q, q, sl);
@@ -125,8 +125,13 @@ extern "C" int wm_mse_metrics_f32(const float *pred, const float *y, int B, int6
     const int grid = loss_grid((long long)B * P);
     hipStream_t st = (hipStream_t)stream;
     double *partial = (double *)workspace;
-    hipLaunchKernelGGL(mse_metrics_kernel, dim3(grid), dim3(BLOCK), 0, st, pred, y, B, (long long)P,
-                       broadcast, eps, gscale, grad, partial);
+    WM_REQUIRE(eps > 0.0f, WM_ERR_INVALID, "wm_mse_metrics_f32: eps must be positive (the clip of msle)");
+    if ((long long)B * P + (long long)grid * BLOCK < (1ll << 31))
+        hipLaunchKernelGGL(mse_metrics_kernel<unsigned>, dim3(grid), dim3(BLOCK), 0, st, pred, y, B,
+                           (long long)P, broadcast, eps, gscale, grad, partial);
+    else
+        hipLaunchKernelGGL(mse_metrics_kernel<long long>, dim3(grid), dim3(BLOCK), 0, st, pred, y, B,
+                           (long long)P, broadcast, eps, gscale, grad, partial);
     WM_LAUNCH_CHECK("mse_metrics_kernel");
     hipLaunchKernelGGL(mse_metrics_finalize_kernel, dim3(3), dim3(64), 0, st, partial, grid,
                        1.0 / count, out3);
