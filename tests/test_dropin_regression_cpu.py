@@ -289,3 +289,31 @@ def test_model_module_has_no_import_side_effects_and_learns_xor(capsys):
     assert h.epoch == [0, 1] and set(h.history) >= {"loss", "val_loss", "accuracy"}
     assert m.predict(np.array([[0, 0], [1, 0], [0, 1], [1, 1]])).shape == (4, 1)
     assert len(m.evaluate(x, y, batch_size=2)) == 3
+
+
+def test_generator_advance_by_is_the_loop_in_closed_form():
+    """``_advance_by(count)`` (what ``device_rows`` uses: a fit of 262 144 steps per epoch spent
+    0.37 s per pass in the per-batch loop) against ``count`` calls of ``_advance``, whose tuple
+    assignment makes every entry of the region index lag the one before it by a step
+    (multipleRegression.py:259-270, singleRegression.py:302-312); from arbitrary states."""
+    import random
+    from weather_model_amd.dropin import multipleRegression as mr, singleRegression as sr
+
+    random.seed(2)
+    for cls, idx, reg in ((mr.WeatherDataGenerator, "index", "region_index"),
+                          (sr.WeatherGenerator, "index", "regionIndex")):
+        for _ in range(200):
+            L, d = random.randint(1, 7), (1, random.randint(1, 4), random.randint(1, 4), 3)
+            a, b = cls.__new__(cls), cls.__new__(cls)
+            for g in (a, b):
+                g.length = L
+                g.data_dim = g.dsDim = d
+            state = (random.randint(0, 60), tuple(random.randint(0, 9) for _ in range(3)))
+            for g in (a, b):
+                setattr(g, idx, state[0])
+                setattr(g, reg, state[1])
+            for count in (random.randint(0, 50) for _ in range(5)):
+                for _ in range(count):
+                    a._advance()
+                b._advance_by(count)
+                assert (getattr(a, idx), getattr(a, reg)) == (getattr(b, idx), getattr(b, reg))

@@ -290,6 +290,10 @@ class LinearStackModel:
                 getattr(source, "device_ready", lambda: False)():
             if steps is None:
                 raise ValueError("steps_per_epoch / validation_steps is required for a generator")
+            if chunk_rows is None:
+                # rows built on the device: chunks of ~1 GiB, so that the two launches per chunk
+                # (gather, Gram or metrics: ~0.2 ms of GPU time) outlast the host work between them
+                chunk_rows = max(1 << 16, (1 << 30) // (4 * (self.F + self.P)))
             per = max(1, int(chunk_rows) // max(1, int(source.rows_per_batch())))
             state = source.get_state()
 
@@ -308,7 +312,8 @@ class LinearStackModel:
                 run(fn)
                 source.set_state(end_state)
             return replay
-        store = _RowStore(self.F, self.P, self.device, chunk_rows, on_chunk, keep_rows_up_to)
+        store = _RowStore(self.F, self.P, self.device, chunk_rows or 1 << 18, on_chunk,
+                          keep_rows_up_to)
         for batch in _batches(source, steps):
             store.add(*_as_rows(*batch))
         store.flush()
@@ -323,7 +328,7 @@ class LinearStackModel:
 
     def fit(self, x=None, y=None, batch_size=None, epochs=1, verbose=1, callbacks=None,
             validation_split=0.0, validation_data=None, shuffle=True, steps_per_epoch=None,
-            validation_steps=None, chunk_rows=1 << 18, ridge=None,
+            validation_steps=None, chunk_rows=None, ridge=None,
             max_resident_rows=1 << 26, **kwargs):
         """Least-squares fit, one Gram pass + one solve per epoch (see the module docstring).
 

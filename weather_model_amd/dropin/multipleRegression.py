@@ -199,6 +199,19 @@ class WeatherDataGenerator:
                              self.region_index[0] // self.data_dim[1],
                              self.region_index[1] // self.data_dim[2])
 
+    def _advance_by(self, count):
+        """``count`` times ``_advance`` in closed form: after step t, region_index is
+        (i_t // L, (i_{t-1} // L) // d1, ((i_{t-2} // L) // d1) // d2) -- every entry lags the one
+        before it by a step, as the reference's tuple assignment has it (:259-270)."""
+        count = int(count)
+        if count < 3:
+            for _ in range(count):
+                self._advance()
+            return
+        i, L, d1, d2 = self.index + count, self.__len__(), self.data_dim[1], self.data_dim[2]
+        self.index = i
+        self.region_index = (i // L, ((i - 1) // L) // d1, (((i - 2) // L) // d1) // d2)
+
     def __call__(self):
         while True:                     # repeats over the data for ever (:259-270)
             yield self.__getitem__(self.index % self.__len__(), self._region())
@@ -234,7 +247,10 @@ class WeatherDataGenerator:
         once per generator."""
         import torch
         vol = getattr(self, "_vol", None)
-        if vol is None or vol.device != torch.device(device):
+        want = torch.device(device)
+        if want.type == "cuda" and want.index is None:        # "cuda" names the current device:
+            want = torch.device("cuda", torch.cuda.current_device())   # compare like with like
+        if vol is None or vol.device != want:
             tested = [d for d in DATA_VARS if VARIABLE_TEST[self.iteration][d]]
             host = np.stack([np.stack([np.asarray(f[d][0], dtype=np.float32) for d in tested])
                              for f in self.all_data])
@@ -243,9 +259,9 @@ class WeatherDataGenerator:
                 # (Z, Y, X, files, vars), the rows of a batch (consecutive files at one grid point)
                 # are one contiguous read; the kernel sees the same logical axes through strides
                 stored = torch.from_numpy(np.ascontiguousarray(host.transpose(2, 3, 4, 0, 1)))
-                vol = stored.to(device).permute(3, 4, 0, 1, 2)
+                vol = stored.to(want).permute(3, 4, 0, 1, 2)
             else:
-                vol = torch.from_numpy(np.ascontiguousarray(host)).to(device)
+                vol = torch.from_numpy(np.ascontiguousarray(host)).to(want)
             self._vol = vol
         return vol
 
@@ -260,8 +276,7 @@ class WeatherDataGenerator:
                 "region": self.region_index, "dims": tuple(self.data_dim[1:4])}
         X, Y = ops.gather_cubes(vol, (c, c, c), TIME_SPAN // 2, TIME_SPAN, int(count) * bs,
                                 walk=walk)
-        for _ in range(int(count)):
-            self._advance()
+        self._advance_by(count)
         return X, Y
 
 

@@ -232,6 +232,18 @@ class WeatherGenerator:
                             self.regionIndex[0] // self.dsDim[1],
                             self.regionIndex[1] // self.dsDim[2])
 
+    def _advance_by(self, count):
+        """``count`` times ``_advance`` in closed form (every entry of regionIndex lags the one
+        before it by a step, as the reference's tuple assignment has it)."""
+        count = int(count)
+        if count < 3:
+            for _ in range(count):
+                self._advance()
+            return
+        i, L, d1, d2 = self.index + count, self.__len__(), self.dsDim[1], self.dsDim[2]
+        self.index = i
+        self.regionIndex = (i // L, ((i - 1) // L) // d1, (((i - 2) // L) // d1) // d2)
+
     def __call__(self):
         while True:
             region = (self.regionIndex[0] % self.dsDim[1],
@@ -273,8 +285,7 @@ class WeatherGenerator:
                 "region": self.regionIndex, "dims": tuple(self.dsDim[1:4])}
         X, Y = ops.gather_cubes(self._vol, (CUBE_SIZE,) * 3, 1, 2, int(count) * self.batchSize,
                                 walk=walk)
-        for _ in range(int(count)):
-            self._advance()
+        self._advance_by(count)
         return X, Y
 
 
