@@ -133,9 +133,23 @@ class DataGenerator:
         """``__getitem__`` with the cubes cut on the GPU (wm_gather_cubes_f32 with explicit
         origins): the SAME ``random.randint`` draws in the same order, so a seeded run yields bit
         for bit the batches of the host path -- as device tensors."""
+        import torch
         from weather_model_amd import ops
         n_t, n_z, n_y, n_x = self.data_shape
-        origins = np.empty((BATCH_SIZE, 4), dtype=np.int32)
+        vol = self.device_volume()
+        # the 16 origins go up through a small ring of PINNED buffers with an asynchronous copy: a
+        # pageable upload blocks the host until the stream's queued work (the previous training
+        # step) has drained, which took the fit loop from 0.37 to 0.47 ms per step
+        ring = self.__dict__.setdefault("_origin_ring", [])
+        if not ring:
+            for _ in range(4):
+                ring.append((torch.empty((BATCH_SIZE, 4), dtype=torch.int32, pin_memory=True),
+                             torch.empty((BATCH_SIZE, 4), dtype=torch.int32, device=vol.device),
+                             torch.cuda.Event()))
+        self._origin_next = (self.__dict__.get("_origin_next", -1) + 1) % len(ring)
+        pinned, on_dev, copied = ring[self._origin_next]
+        copied.synchronize()                      # its last upload has left the pinned buffer
+        origins = pinned.numpy()
         for b in range(BATCH_SIZE):
             origins[b] = ((self.index // (n_x * n_y * n_z)) % n_t,
                           (self.index // (n_x * n_y)) % n_z,
@@ -144,8 +158,10 @@ class DataGenerator:
             self.index += random.randint(0, self.__len__() - 1)
             self.index %= self.__len__()
         cube = (INPUT_SHAPE[2], INPUT_SHAPE[1], INPUT_SHAPE[0])
-        x1, x2, y = ops.gather_cubes(self.device_volume(), cube, 2, 4, BATCH_SIZE,
-                                     origins=origins, separate=True)
+        on_dev.copy_(pinned, non_blocking=True)
+        copied.record()
+        x1, x2, y = ops.gather_cubes(vol, cube, 2, 4, BATCH_SIZE, origins=origins, separate=True,
+                                     origins_device=on_dev)
         nv = len(DATA_VARIABLES)
         return (x1.view(BATCH_SIZE, nv, *cube), x2.view(BATCH_SIZE, nv, *cube),
                 y.view(BATCH_SIZE, nv, -1))

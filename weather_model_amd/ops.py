@@ -681,7 +681,8 @@ def gather_triplets(vol, shape, indices=None, first=0, count=None, time_offset=0
     return xout, yout
 
 
-def gather_cubes(vol, cube, d_mid, d_end, rows, origins=None, walk=None, separate=False):
+def gather_cubes(vol, cube, d_mid, d_end, rows, origins=None, walk=None, separate=False,
+                 origins_device=None):
     """Rows of the regression / Conv3D generators from a resident (files, nvars, Z, Y, X) volume
     (``wm_gather_cubes_f32``).  ``cube`` = (cz, cy, cx).  Either ``origins`` -- an int32 (rows, 4)
     tensor/array of (file, z0, y0, x0) -- or ``walk`` = dict(batch, length, index, region=(r0,r1,r2),
@@ -689,6 +690,9 @@ def gather_cubes(vol, cube, d_mid, d_end, rows, origins=None, walk=None, separat
     ``vol`` may be any strided view with that logical shape (``wm_gather_cubes_strided_f32``): a
     volume stored point-major, ``stored.permute(3, 4, 0, 1, 2)`` of a (Z, Y, X, files, nvars)
     tensor, turns the 4-byte gathers of cube-1 rows into contiguous reads.
+    ``origins_device``: the same origins already on the device (int32, contiguous) -- ``origins``
+    is then only checked on the host and not uploaded again (a pageable upload per call stalls the
+    host behind the stream's queued work).
     Returns (X (rows, 2p), Y (rows, p)), or (x1 (rows, p), x2 (rows, p), Y) with ``separate``."""
     if not isinstance(vol, torch.Tensor) or not vol.is_cuda or vol.dtype != torch.float32:
         raise RuntimeError("volume must be a float32 CUDA tensor (there is no CPU fallback)")
@@ -713,15 +717,22 @@ def gather_cubes(vol, cube, d_mid, d_end, rows, origins=None, walk=None, separat
     if rows > 0:
         dmax = max(int(d_mid), int(d_end))
         if origins is not None:
-            o = torch.as_tensor(origins)
-            if o.shape != (rows, 4):
-                raise ValueError(f"origins must be (rows, 4), got {tuple(o.shape)}")
-            lo = o.min(dim=0).values.tolist()
-            hi = o.max(dim=0).values.tolist()
+            oh = origins.cpu().numpy() if isinstance(origins, torch.Tensor) else np.asarray(origins)
+            if oh.shape != (rows, 4):
+                raise ValueError(f"origins must be (rows, 4), got {tuple(oh.shape)}")
+            lo = oh.min(axis=0).tolist()
+            hi = oh.max(axis=0).tolist()
             if min(lo) < 0 or hi[0] + dmax >= files or hi[1] + cz > Z or hi[2] + cy > Y or \
                     hi[3] + cx > X:
                 raise ValueError("a cube origin leaves the volume")
-            o = o.to(device=dev, dtype=torch.int32).contiguous()
+            if origins_device is not None:
+                o = origins_device
+                if o.device != dev or o.dtype != torch.int32 or tuple(o.shape) != (rows, 4) or \
+                        not o.is_contiguous():
+                    raise ValueError("origins_device must be a contiguous int32 (rows, 4) tensor on "
+                                     "the volume's device")
+            else:
+                o = torch.from_numpy(np.ascontiguousarray(oh, dtype=np.int32)).to(dev)
             args = (o.data_ptr(), rows, 1, 1, 0, 0, 0, 0, 1, 1, 1)
         else:
             r0, r1, r2 = (int(v) for v in walk["region"])
