@@ -269,13 +269,25 @@ class DeviceTrainer:
         dev = self.flat.device
         n = len(dataset)
         world, rank = self._dp.world(), self._dp.rank()
-        gen = torch.Generator(device="cpu").manual_seed(seed)
-        order = (torch.randperm(n, generator=gen) if shuffle else torch.arange(n)).to(dev)
+        if not shuffle:
+            order = torch.arange(n, device=dev)
+        elif dev.type == "cuda":
+            # drawn on the device (every rank draws the same permutation from the same seed): the
+            # host draw took 17 ms per epoch of 3.1e6 samples, as long as the epoch's kernels
+            order = torch.randperm(n, generator=torch.Generator(device=dev).manual_seed(seed),
+                                   device=dev)
+        else:
+            order = torch.randperm(n, generator=torch.Generator(device="cpu").manual_seed(seed))
         total = torch.zeros((), device=dev)
         batches = 0
         for start in range(0, n, batch_size):
             idx = order[start:start + batch_size]
             mine = idx[rank::world]                      # this rank's share of the global batch
+            if shuffle and mine.numel() >= 4096:
+                # a batch's loss and gradient are sums over its samples: taking the (random) batch
+                # in index order changes no term, and the fused kernel's gather then walks the
+                # volume forwards (batch 1 038 240: 5.0 -> 2.9 ms)
+                mine = mine.sort().values
             # A rank whose share is empty (last batch smaller than the world) still takes part in
             # the collective, the Adam step and the batch count -- with a zero gradient and a zero
             # loss share.  Skipping it would pair this rank's NEXT collective with the others'
