@@ -430,8 +430,11 @@ def run_gram(F, n_rows, steps, warmup, rank, world, cpu_base, P=1, dist="uniform
         res["solve_ms_avg"] = float(np.mean([a.elapsed_time(c) for a, c in sevs]))
     kname = gram_kernel_name(F, P)
     # the shapes whose launches are in the stored PMC passes of the default line
-    default_shape = (F, P, n_rows) in ((16, 1, 100_000_000), (2, 1, 400_000_000), (432, 216, 1_000_000))
+    default_shape = (F, P, n_rows) in ((16, 1, 100_000_000), (2, 1, 400_000_000), (432, 216, 1_000_000),
+                                       (16, 8, 100_000_000))
+    nq = 2 if F + P + 1 <= 32 else 4
     pkey = {"gram_small_kernel": f"gram_small_kernel<{F}, {P}>",
+            "gram_mid_kernel": f"gram_mid_kernel<{nq}, {'true' if F % nq == 0 and P % nq == 0 else 'false'}>",
             "gram_syrk_kernel": "gram_syrk_kernel<true, 2>"}.get(kname, kname)
     gbs = bytes_per_row * n_rows / kavg / 1e9
     tf = flops_per_row * n_rows / kavg / 1e12
@@ -447,6 +450,34 @@ def run_gram(F, n_rows, steps, warmup, rank, world, cpu_base, P=1, dist="uniform
                             "kernel": kname, "algorithmic_bytes_per_row": bytes_per_row,
                             "algorithmic_flops_per_row": flops_per_row,
                             "TFLOPs_algorithmic": tf})
+    if P > 1 or F == 2:
+        # the other half of an epoch of the drop-ins' fit: loss / mae / msle of the solved
+        # coefficients over the same resident rows (multipleRegression.py:292-296), one fused pass
+        sums = torch.zeros((4,), device="cuda", dtype=torch.float64)
+        mev = []
+        for i in range(3 + min(steps, 10)):
+            e = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            e[0].record()
+            ops.linear_metrics(X, Y, plan.beta, sums.zero_())
+            e[1].record()
+            if i >= 3:
+                mev.append(e)
+        torch.cuda.synchronize()
+        mms = float(np.mean([a.elapsed_time(c) for a, c in mev]))
+        fused = bool(L.wm_linear_metrics_supported(F, P))
+        mgbs = bytes_per_row * n_rows / mms / 1e6
+        res["fit_metrics"] = {
+            "ms": mms, "mse": float(sums[0] / sums[3]), "mae": float(sums[1] / sums[3]),
+            "msle": float(sums[2] / sums[3]), "epoch_ms": total / steps * 1e3 + mms,
+            "roofline": {"bound": "hbm", "achieved": mgbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": mgbs / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "linear_metrics_staged_kernel / linear_metrics_kernel",
+                         "algorithmic_bytes_per_row": bytes_per_row} if fused else
+                        {"bound": "mfma", "achieved": 2.0 * F * P * n_rows / mms / 1e9,
+                         "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                         "frac": 2.0 * F * P * n_rows / mms / 1e9 / MFMA_F32_PEAK_TF, "traffic": None,
+                         "kernel": "library GEMM (predictions) + residual_sums_kernel",
+                         "algorithmic_flops_per_row": 2 * F * P}}
     if cpu_base and rank == 0 and world == 1:
         res.update(gram_cpu_baselines(X, Y, F, P, beta))
     del X, Y
@@ -1345,7 +1376,7 @@ def main():
                         "ms_per_step": r["ms_per_step"], "roofline": r["roofline"],
                         "config": r["config"], "kernel_ms_avg": r["kernel_ms_avg"],
                         "planted_coef_max_err": r["planted_coef_max_err"]})
-            for k in ("cpu_baseline", "cpu_baseline_port", "solve_ms_avg", "exchange_us"):
+            for k in ("cpu_baseline", "cpu_baseline_port", "solve_ms_avg", "exchange_us", "fit_metrics"):
                 if k in r:
                     out[k] = r[k]
         else:
