@@ -122,7 +122,11 @@ __global__ __launch_bounds__(BLOCK) void linear_metrics_kernel(const float *__re
 // 4F + 16 bytes apart, so the per-lane row reads that follow (ds_read_b128, lane = row) hit all 64
 // banks.  Wave-private, so no workgroup barrier in the loop: LDS executes a wave's instructions in
 // order.  Y goes the same way when its rows are whole 16-byte pieces (VECY).
-template <int PT, bool VECY>
+// SB (P == PT): beta is read straight from global memory at wave-uniform addresses -- scalar loads
+// into SGPRs, which the float64 FMAs take as an operand -- instead of 4 PT/2 broadcast LDS reads per
+// feature: the LDS pipe (76 16-byte operations per 64 rows at F=16, P=8, of which 64 were beta) was
+// the tightest of the kernel's three limits.
+template <int PT, bool VECY, bool SB>
 __global__ __launch_bounds__(BLOCK) void linear_metrics_staged_kernel(
     const float *__restrict__ X, const float *__restrict__ Y, const double *__restrict__ beta, long long n,
     int F, int P, int msle, float eps, int beta_bytes, double *__restrict__ partial)
@@ -134,11 +138,13 @@ __global__ __launch_bounds__(BLOCK) void linear_metrics_staged_kernel(
     const int wave_bytes = 64 * xstride + (VECY ? 64 * ystride : 0);
     char *xs = reinterpret_cast<char *>(sb) + beta_bytes + wv * wave_bytes;
     char *ys = xs + 64 * xstride;
-    for (int e = threadIdx.x; e < (F + 1) * PT; e += BLOCK) {
-        const int f = e / PT, p = e - f * PT;
-        sb[e] = p < P ? beta[f * P + p] : 0.0;
+    if (!SB) {
+        for (int e = threadIdx.x; e < (F + 1) * PT; e += BLOCK) {
+            const int f = e / PT, p = e - f * PT;
+            sb[e] = p < P ? beta[f * P + p] : 0.0;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     // piece q = lane + 64 k of a tile lives in row q / Q at piece q % Q: walked incrementally
     const int dx = 64 / QX, mx = 64 % QX, r0x = lane / QX, p0x = lane % QX;
     const int dy = VECY ? 64 / QY : 0, my = VECY ? 64 % QY : 0, r0y = VECY ? lane / QY : 0,
@@ -196,13 +202,13 @@ __global__ __launch_bounds__(BLOCK) void linear_metrics_staged_kernel(
         __builtin_amdgcn_wave_barrier();
         double s[PT];
 #pragma unroll
-        for (int p = 0; p < PT; ++p) s[p] = sb[F * PT + p];
+        for (int p = 0; p < PT; ++p) s[p] = SB ? beta[F * PT + p] : sb[F * PT + p];
         for (int f0 = 0; f0 < F; f0 += 4) {
             const f32x4 x = *reinterpret_cast<const f32x4 *>(xrow + f0 * 4);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const double xd = (double)x[j];
-                const double *b = sb + (f0 + j) * PT;
+                const double *b = (SB ? beta : sb) + (f0 + j) * PT;
 #pragma unroll
                 for (int p = 0; p < PT; ++p) s[p] = fma(xd, b[p], s[p]);
             }
@@ -319,8 +325,16 @@ extern "C" int wm_linear_metrics_f32(const float *X, const float *Y, const doubl
         grid = (int)(want < cap ? want : cap);
         if (grid < 1) grid = 1;
 #define LM_STAGED(PT_, VY_)                                                                      \
-    hipLaunchKernelGGL((linear_metrics_staged_kernel<PT_, VY_>), dim3(grid), dim3(BLOCK), staged_lds, \
-                       st, X, Y, beta, (long long)n, F, P, want_msle, msle_eps, (int)beta_bytes, partial)
+    {                                                                                            \
+        if (P == PT_ && (PT_ == 8 || PT_ == 1))  /* measured: 6 columns lose (odd row pieces) */  \
+            hipLaunchKernelGGL((linear_metrics_staged_kernel<PT_, VY_, true>), dim3(grid), dim3(BLOCK), \
+                               staged_lds, st, X, Y, beta, (long long)n, F, P, want_msle, msle_eps,   \
+                               (int)beta_bytes, partial);                                        \
+        else                                                                                     \
+            hipLaunchKernelGGL((linear_metrics_staged_kernel<PT_, VY_, false>), dim3(grid),      \
+                               dim3(BLOCK), staged_lds, st, X, Y, beta, (long long)n, F, P,      \
+                               want_msle, msle_eps, (int)beta_bytes, partial);                   \
+    }
         if (vecy) {
             switch (PT) {
             case 4: LM_STAGED(4, true); break;
