@@ -68,7 +68,7 @@ __device__ __forceinline__ void lm_block_out(double sse, double sae, double sle,
     }
 }
 
-template <int PT, bool VEC4>
+template <int PT, int VEC>          // VEC: floats per load of a row of X (4: F % 4 == 0, 2: F % 2 == 0)
 __global__ __launch_bounds__(BLOCK) void linear_metrics_kernel(const float *__restrict__ X,
                                                               const float *__restrict__ Y,
                                                               const double *__restrict__ beta,
@@ -88,11 +88,23 @@ __global__ __launch_bounds__(BLOCK) void linear_metrics_kernel(const float *__re
 #pragma unroll
         for (int p = 0; p < PT; ++p) s[p] = sb[F * PT + p];
         const float *xr = X + row * F;
-        if (VEC4) {
+        if (VEC == 4) {
             for (int f0 = 0; f0 < F; f0 += 4) {
                 const f32x4 x = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(xr + f0));
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
+                    const double xd = (double)x[j];
+                    const double *b = sb + (f0 + j) * PT;
+#pragma unroll
+                    for (int p = 0; p < PT; ++p) s[p] = fma(xd, b[p], s[p]);
+                }
+            }
+        } else if (VEC == 2) {
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            for (int f0 = 0; f0 < F; f0 += 2) {
+                const f32x2 x = __builtin_nontemporal_load(reinterpret_cast<const f32x2 *>(xr + f0));
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
                     const double xd = (double)x[j];
                     const double *b = sb + (f0 + j) * PT;
 #pragma unroll
@@ -361,11 +373,14 @@ extern "C" int wm_linear_metrics_f32(const float *X, const float *Y, const doubl
 #define LM_LAUNCH(PT_)                                                                           \
     {                                                                                            \
         if (vec)                                                                                 \
-            hipLaunchKernelGGL((linear_metrics_kernel<PT_, true>), dim3(grid), dim3(BLOCK), lds, st, X, \
-                               Y, beta, (long long)n, F, P, want_msle, msle_eps, partial);       \
+            hipLaunchKernelGGL((linear_metrics_kernel<PT_, 4>), dim3(grid), dim3(BLOCK), lds, st, X, Y, \
+                               beta, (long long)n, F, P, want_msle, msle_eps, partial);          \
+        else if (F % 2 == 0 && (((uintptr_t)X) & 7) == 0)                                        \
+            hipLaunchKernelGGL((linear_metrics_kernel<PT_, 2>), dim3(grid), dim3(BLOCK), lds, st, X, Y, \
+                               beta, (long long)n, F, P, want_msle, msle_eps, partial);          \
         else                                                                                     \
-            hipLaunchKernelGGL((linear_metrics_kernel<PT_, false>), dim3(grid), dim3(BLOCK), lds, st, \
-                               X, Y, beta, (long long)n, F, P, want_msle, msle_eps, partial);    \
+            hipLaunchKernelGGL((linear_metrics_kernel<PT_, 1>), dim3(grid), dim3(BLOCK), lds, st, X, Y, \
+                               beta, (long long)n, F, P, want_msle, msle_eps, partial);          \
     }
         switch (PT) {
         case 1: LM_LAUNCH(1) break;
