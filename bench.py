@@ -465,17 +465,23 @@ def run_gram(F, n_rows, steps, warmup, rank, world, cpu_base, P=1, dist="uniform
         torch.cuda.synchronize()
         mms = float(np.mean([a.elapsed_time(c) for a, c in mev]))
         fused = bool(L.wm_linear_metrics_supported(F, P))
+        mkey = {(16, 8): "linear_metrics_staged_kernel<8, true, true>",
+                (2, 1): "linear_metrics_kernel<1, 2>"}.get((F, P), "residual_sums_kernel")
         mgbs = bytes_per_row * n_rows / mms / 1e6
         res["fit_metrics"] = {
             "ms": mms, "mse": float(sums[0] / sums[3]), "mae": float(sums[1] / sums[3]),
             "msle": float(sums[2] / sums[3]), "epoch_ms": total / steps * 1e3 + mms,
             "roofline": {"bound": "hbm", "achieved": mgbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": mgbs / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "linear_metrics_staged_kernel / linear_metrics_kernel",
+                         "frac": mgbs / HBM_PEAK_GBS, "traffic": pmc_traffic([mkey], default_shape),
+                         "traffic_source": pmc_source([mkey], default_shape),
+                         "kernel": mkey,
                          "algorithmic_bytes_per_row": bytes_per_row} if fused else
                         {"bound": "mfma", "achieved": 2.0 * F * P * n_rows / mms / 1e9,
                          "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                         "frac": 2.0 * F * P * n_rows / mms / 1e9 / MFMA_F32_PEAK_TF, "traffic": None,
+                         "frac": 2.0 * F * P * n_rows / mms / 1e9 / MFMA_F32_PEAK_TF,
+                         "traffic": pmc_traffic([mkey], default_shape),
+                         "traffic_source": pmc_source([mkey], default_shape),
+                         "traffic_note": "residual_sums_kernel only (the GEMM is the library's)",
                          "kernel": "library GEMM (predictions) + residual_sums_kernel",
                          "algorithmic_flops_per_row": 2 * F * P}}
     if cpu_base and rank == 0 and world == 1:
