@@ -406,3 +406,28 @@ def test_linear_metrics_rejects_bad_shapes():
     s = ops.linear_metrics(X[:0], torch.zeros((0, 2), device="cuda"),
                            torch.zeros((5, 2), device="cuda", dtype=torch.float64))
     assert s.tolist() == [0.0, 0.0, 0.0, 0.0]
+
+
+def test_linear_metrics_full_size_properties():
+    """4e7 rows of F=16, P=8 (the size the Gram tests use): with Y = X beta + c + uniform noise of
+    standard deviation s the fused pass must report mse = s^2 and mae = s sqrt(3) / 2 (the mean
+    absolute value of that uniform) to sampling accuracy, the exact count, and the same sums whether
+    the rows go through in one call or accumulate over uneven chunks (1e-12: different partial
+    orders)."""
+    from weather_model_amd import ops
+    n, F, P, s = 40_000_000, 16, 8, 0.01
+    X = ops.synth_uniform((n, F), seed=41)
+    beta = torch.from_numpy(np.random.default_rng(7).uniform(-0.5, 0.5, (F + 1, P))).cuda()
+    Y = ops.synth_uniform((n, P), seed=42, lo=-s * 3 ** 0.5, hi=s * 3 ** 0.5)
+    step = 4_000_000
+    for a in range(0, n, step):
+        Y[a:a + step] += (X[a:a + step].double() @ beta[:F] + beta[F]).float()
+    one = ops.linear_metrics(X, Y, beta).cpu().numpy()
+    assert one[3] == n * P
+    assert one[0] / one[3] == pytest.approx(s * s, rel=5e-3)
+    assert one[1] / one[3] == pytest.approx(s * 3 ** 0.5 / 2, rel=5e-3)
+    assert 0 < one[2] / one[3] < s * s            # log1p compresses: msle below mse for values >= 0
+    acc = None
+    for a, b in ((0, 13_000_001), (13_000_001, 13_000_064), (13_000_064, n)):
+        acc = ops.linear_metrics(X[a:b], Y[a:b], beta, sums=acc)
+    np.testing.assert_allclose(acc.cpu().numpy(), one, rtol=1e-12)
