@@ -350,6 +350,8 @@ def gram_kernel_name(F, P):
         return "gram_x64_kernel"
     if F + P <= 15:
         return "gram_small_kernel"
+    if (F, P) in ((16, 8), (16, 4), (8, 8)):
+        return "gram_quad_kernel"
     return "gram_mid_kernel" if F + P + 1 <= 64 else "gram_syrk_kernel"
 
 
@@ -435,6 +437,7 @@ def run_gram(F, n_rows, steps, warmup, rank, world, cpu_base, P=1, dist="uniform
     nq = 2 if F + P + 1 <= 32 else 4
     pkey = {"gram_small_kernel": f"gram_small_kernel<{F}, {P}>",
             "gram_mid_kernel": f"gram_mid_kernel<{nq}, {'true' if F % nq == 0 and P % nq == 0 else 'false'}>",
+            "gram_quad_kernel": f"gram_quad_kernel<{F // 4}, {P // 4}>",
             "gram_syrk_kernel": "gram_syrk_kernel<true, 2>"}.get(kname, kname)
     gbs = bytes_per_row * n_rows / kavg / 1e9
     tf = flops_per_row * n_rows / kavg / 1e12

@@ -431,3 +431,39 @@ def test_linear_metrics_full_size_properties():
     for a, b in ((0, 13_000_001), (13_000_001, 13_000_064), (13_000_064, n)):
         acc = ops.linear_metrics(X[a:b], Y[a:b], beta, sums=acc)
     np.testing.assert_allclose(acc.cpu().numpy(), one, rtol=1e-12)
+
+
+@pytest.mark.parametrize("F,P", [(16, 8), (16, 4), (8, 8)], ids=lambda v: str(v))
+def test_gram_quad_kernel_exact_tails_and_flush(F, P):
+    """gram_quad.hip (rows of four equal pieces; eight variables at once = F=16, P=8): exact on
+    integers for row counts around the 16-row tile, the 8-tile batch and more than one batch per
+    wave (2048 waves x 128 rows); pointers off their alignment take another kernel and must agree;
+    4e7 random rows cross the float32 -> float64 flush (1024 tiles per wave) and are checked against
+    a float64 product formed in chunks on the device."""
+    from weather_model_amd import ops, synth
+    from oracle import cpu as ocpu
+    for n in (1, 15, 16, 17, 127, 128, 129, 2048 * 128 + 5, 1_000_003):
+        X, Y = _int_problem(n, F, P)
+        ref = ocpu.gram(X, Y)
+        a = ops.gram(_dev(X), _dev(Y)).cpu().numpy()
+        assert np.array_equal(a, ref), (F, P, n, np.argwhere(a != ref)[:4])
+    bx = torch.zeros(n * F + 1, device="cuda")
+    by = torch.zeros(n * P + 1, device="cuda")
+    bx[1:] = _dev(X).reshape(-1)
+    by[1:] = _dev(Y).reshape(-1)
+    assert np.array_equal(ops.gram(bx[1:].view(n, F), by[1:].view(n, P)).cpu().numpy(), ref)
+    n = 40_000_000
+    Xd = ops.synth_uniform((n, F), seed=51)
+    Yd = ops.synth_uniform((n, P), seed=52, lo=-1.0, hi=2.0)
+    a = ops.gram(Xd, Yd)
+    assert torch.equal(ops.gram(Xd, Yd), a)                       # bitwise reproducible
+    D = F + 1 + P
+    ref = torch.zeros((D, D), device="cuda", dtype=torch.float64)
+    for s0 in range(0, n, 2_000_000):
+        Z = torch.cat([Xd[s0:s0 + 2_000_000].double(),
+                       torch.ones((min(2_000_000, n - s0), 1), device="cuda", dtype=torch.float64),
+                       Yd[s0:s0 + 2_000_000].double()], 1)
+        ref += Z.T @ Z
+    assert a[F, F].item() == n
+    assert relinf(a.cpu().numpy(), ref.cpu().numpy()) < 2e-6
+    assert torch.equal(a, a.T)

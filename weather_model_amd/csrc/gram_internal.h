@@ -2,6 +2,8 @@
 //   gram.hip        F = 16 / F = 64 with P = 1 (BASELINE configs 2 and 5), the solve, predict
 //   gram_small.hip  F + P <= 15 on the VALU, HBM-bound streaming (the reference's own
 //                   multipleRegression shape F = 2, P = 1: multipleRegression.py:35,273-286)
+//   gram_quad.hip   F = 4 RX, P = 4 RY for a few (RX, RY) (eight variables at once: F = 16, P = 8):
+//                   gram_f16's 4x4x1 MFMA scheme with Y as further operand registers, HBM-bound
 //   gram_mid.hip    F + P + 1 <= 64 otherwise: operands straight from global memory into MFMA
 //                   registers, any alignment (the drop-ins' multi-variable fits, F = 2p, P = p)
 //   gram_syrk.hip   every other shape: LDS-staged blocked Z'Z on fp32 MFMA (the reference's
@@ -27,3 +29,10 @@ bool wm_gram_mid_supported(int F, int P);
 size_t wm_gram_mid_workspace_bytes(int F, int P);
 int wm_gram_mid_launch(const float *X, const float *Y, long long n, int F, int P, double *acc,
                        double *slabs, hipStream_t st);
+
+// (F, P) in {(16,8), (16,4), (8,8), (8,4)}, X aligned to F bytes, Y to P bytes.  Workspace:
+// per-workgroup float64 partials.
+bool wm_gram_quad_supported(const float *X, const float *Y, int F, int P);
+size_t wm_gram_quad_workspace_bytes(int F, int P);
+int wm_gram_quad_launch(const float *X, const float *Y, long long n, int F, int P, double *acc,
+                        double *partial, hipStream_t st);
