@@ -468,8 +468,8 @@ def run_gram(F, n_rows, steps, warmup, rank, world, cpu_base, P=1, dist="uniform
         torch.cuda.synchronize()
         mms = float(np.mean([a.elapsed_time(c) for a, c in mev]))
         fused = bool(L.wm_linear_metrics_supported(F, P))
-        mkey = {(16, 8): "linear_metrics_staged_kernel<8, true, true>",
-                (2, 1): "linear_metrics_kernel<1, 2>"}.get((F, P), "residual_sums_kernel")
+        mkey = {(16, 8): "linear_metrics_tile_kernel<4, 8, true>",
+                (2, 1): "linear_metrics_small_kernel<2, 1, true>"}.get((F, P), "residual_sums_kernel")
         mgbs = bytes_per_row * n_rows / mms / 1e6
         res["fit_metrics"] = {
             "ms": mms, "mse": float(sums[0] / sums[3]), "mae": float(sums[1] / sums[3]),

@@ -393,6 +393,49 @@ def test_linear_metrics_match_float64_restatement(shape):
     assert torch.equal(b, sums)
 
 
+@pytest.mark.parametrize("F,P", [(1, 1), (2, 1), (4, 2), (6, 3), (8, 4), (10, 5), (5, 3), (8, 1),
+                                 (16, 8), (12, 6), (32, 16), (16, 4), (8, 8)], ids=lambda v: str(v))
+def test_linear_metrics_stream_kernels_tails_and_far_branch(F, P):
+    """linmetrics.hip's narrow-row kernel (F + P <= 15, gram_small's memory side) and the prefetching
+    tile kernel: row counts around a lane's batch (64 R U rows), a wave's tile (64 rows) and more than
+    one batch per wave; targets UNRELATED to the predictions, so that many outputs take the far form
+    of log1p(a) - log1p(b) (the two differ by more than a factor 1.5) beside near ones in the same
+    wave, plus values below eps and beyond the 1e37 clamp; msle on and off; pointers off their
+    alignment take another kernel and must agree to rounding."""
+    from weather_model_amd import ops
+    rng = np.random.default_rng(F * 31 + P)
+    beta = rng.uniform(-0.5, 0.5, (F + 1, P))
+    beta[F] += 1.0
+    bd = torch.from_numpy(beta).cuda()
+    eps = np.float32(1e-7)
+    for n in (1, 63, 64, 65, 511, 512, 513, 1023, 4097, 2048 * 64 * 4 + 77, 700_001):
+        X = rng.uniform(0.0, 1.0, (n, F)).astype(np.float32)
+        pred = (X.astype(np.float64) @ beta[:F] + beta[F]).astype(np.float32).astype(np.float64)
+        Y = pred.astype(np.float32)
+        far = rng.uniform(size=Y.shape) < 0.3
+        Y[far] = rng.uniform(-0.5, 6.0, int(far.sum())).astype(np.float32)      # far form, some below eps
+        Y += rng.normal(0, 0.01, Y.shape).astype(np.float32)
+        if n > 100:
+            Y[7, 0] = np.float32(3e38)                                          # beyond the clamp
+        Yd = Y.astype(np.float64)
+        d = pred - Yd
+        e = np.log1p(np.clip(pred, eps, 1e37)) - np.log1p(np.clip(Yd, eps, np.float64(np.float32(1e37))))
+        for msle in (True, False):
+            want = np.array([(d * d).sum(), np.abs(d).sum(), (e * e).sum() if msle else 0.0, n * P])
+            Xd, Yt = torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda()
+            got = ops.linear_metrics(Xd, Yt, bd, want_msle=msle).cpu().numpy()
+            assert got[3] == want[3]
+            np.testing.assert_allclose(got[:3], want[:3], rtol=3e-6, atol=1e-12, err_msg=f"{F},{P},{n},{msle}")
+            assert torch.equal(ops.linear_metrics(Xd, Yt, bd, want_msle=msle).cpu(), torch.from_numpy(got))
+            if n in (513, 4097):
+                bx = torch.zeros(n * F + 1, device="cuda")
+                by = torch.zeros(n * P + 1, device="cuda")
+                bx[1:] = Xd.reshape(-1)
+                by[1:] = Yt.reshape(-1)
+                off = ops.linear_metrics(bx[1:].view(n, F), by[1:].view(n, P), bd, want_msle=msle).cpu().numpy()
+                np.testing.assert_allclose(off, got, rtol=3e-6, atol=1e-12)
+
+
 def test_linear_metrics_rejects_bad_shapes():
     from weather_model_amd import ops
     X = torch.zeros((10, 4), device="cuda")

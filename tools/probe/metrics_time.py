@@ -16,7 +16,8 @@ for spec in sys.argv[1:] or ["2:1:40000000", "16:8:40000000", "12:6:40000000", "
     X = ops.synth_uniform((n, F), seed=1)
     Y = ops.synth_uniform((n, P), seed=2)
     beta = torch.rand((F + 1, P), device="cuda", dtype=torch.float64) - 0.5
-    for name, fn in (("fused", lambda: ops.linear_metrics(X, Y, beta)), ("old", lambda: old(X, Y, beta)),
+    for name, fn in (("fused", lambda: ops.linear_metrics(X, Y, beta)),
+                     ("nomsle", lambda: ops.linear_metrics(X, Y, beta, want_msle=False)), ("old", lambda: old(X, Y, beta)),
                      ("gram", lambda: ops.gram(X, Y))):
         if name == "old" and n * P > 4e8:
             continue

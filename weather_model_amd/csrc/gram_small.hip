@@ -16,6 +16,7 @@
 //     wave in float64 (xor butterfly: a fixed order) and kept by lane v % 64; per-workgroup float64
 //     partials, fixed-order finalize (bitwise reproducible).
 #include "gram_internal.h"
+#include "small_stream.h"
 
 namespace {
 
@@ -23,27 +24,17 @@ constexpr int BLOCK = 256;
 constexpr int WAVES = BLOCK / 64;
 constexpr int SM_FLUSH_ROWS = 1024;
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-template <int W> struct VecOf;
-template <> struct VecOf<1> { using T = float; };
-template <> struct VecOf<2> { using T = f32x2; };
-template <> struct VecOf<4> { using T = f32x4; };
-
 template <int F, int P>
 struct SmallCfg {
     static constexpr int M = F + P;                      // non-constant columns of Z = [X | 1 | Y]
     static constexpr int NP = M * (M + 1) / 2;           // products z_i z_j, i <= j
     static constexpr int NV = NP + M;                    // + column sums
-    static constexpr int R = (F % 4 == 0) ? 1 : ((F % 2 == 0) ? 2 : 4);
-    static constexpr int XV = R * F / 4;                 // dwordx4 loads of X per lane and step
-    static constexpr int YN = R * P;                     // floats of Y per lane and step
-    static constexpr int YW = (YN % 4 == 0) ? 4 : ((YN % 2 == 0) ? 2 : 1);
-    static constexpr int YV = YN / YW;
-    static constexpr int U0 = (NV > 100 ? 96 : 48) / (R * M);
+    static constexpr int R0 = (F % 4 == 0) ? 1 : ((F % 2 == 0) ? 2 : 4);
+    static constexpr int U0 = (NV > 100 ? 96 : 48) / (R0 * M);
     static constexpr int U = U0 < 1 ? 1 : (U0 > 8 ? 8 : U0);
-    static constexpr int ROWS_STEP = 64 * R;             // rows a wave takes per step
-    static constexpr int ROWS_BATCH = ROWS_STEP * U;
+    using S = wm_small::Stream<F, P, U>;                 // the memory side (small_stream.h)
+    static constexpr int R = S::R;
+    static constexpr int ROWS_BATCH = S::ROWS_BATCH;
     static constexpr int TOT = (NV + 63) / 64;           // float64 totals per lane
     // waves per SIMD: above ~100 accumulators two register sets of a batch no longer fit in 256
     // VGPRs (F = 10, P = 5: 537 spilled, 2.3 TB/s), so such shapes run one wave per SIMD with 512
@@ -55,12 +46,6 @@ __host__ __device__ constexpr int small_pair(int M, int i, int j)   // i <= j
 {
     return i * M - (i * (i - 1)) / 2 + (j - i);
 }
-
-template <int F, int P>
-struct SmallBuf {
-    f32x4 x[SmallCfg<F, P>::U][SmallCfg<F, P>::XV];
-    float y[SmallCfg<F, P>::U][SmallCfg<F, P>::YN];
-};
 
 template <int F, int P, int NV_, int M_>
 __device__ __forceinline__ void small_row(float (&acc)[NV_], const float (&z)[M_])
@@ -92,37 +77,8 @@ __device__ __forceinline__ void small_flush(float (&acc)[NV_], double (&tot)[TOT
     }
 }
 
-// Loads of batch t (rows t * ROWS_BATCH ...): lane owns R consecutive rows of every step.
-template <int F, int P>
-__device__ __forceinline__ void small_fetch(SmallBuf<F, P> &b, const float *__restrict__ X,
-                                            const float *__restrict__ Y, long long t, int lane)
-{
-    using C = SmallCfg<F, P>;
-    using YT = typename VecOf<C::YW>::T;
-    const f32x4 *__restrict__ Xv = reinterpret_cast<const f32x4 *>(X);
-    const long long row0 = t * C::ROWS_BATCH;
-#pragma unroll
-    for (int u = 0; u < C::U; ++u) {
-        const long long rb = row0 + (long long)u * C::ROWS_STEP;
-        const f32x4 *xs = Xv + (rb * F) / 4 + lane * C::XV;
-#pragma unroll
-        for (int j = 0; j < C::XV; ++j) b.x[u][j] = __builtin_nontemporal_load(xs + j);
-        const YT *ys = reinterpret_cast<const YT *>(Y + rb * P) + lane * C::YV;
-#pragma unroll
-        for (int v = 0; v < C::YV; ++v) {
-            const YT val = __builtin_nontemporal_load(ys + v);
-            if constexpr (C::YW == 1) {
-                b.y[u][v] = val;
-            } else {
-#pragma unroll
-                for (int e = 0; e < C::YW; ++e) b.y[u][v * C::YW + e] = val[e];
-            }
-        }
-    }
-}
-
 template <int F, int P, int NV_>
-__device__ __forceinline__ void small_consume(const SmallBuf<F, P> &b, float (&acc)[NV_])
+__device__ __forceinline__ void small_consume(const wm_small::Buf<typename SmallCfg<F, P>::S> &b, float (&acc)[NV_])
 {
     using C = SmallCfg<F, P>;
 #pragma unroll
@@ -131,9 +87,9 @@ __device__ __forceinline__ void small_consume(const SmallBuf<F, P> &b, float (&a
         for (int r = 0; r < C::R; ++r) {
             float z[C::M];
 #pragma unroll
-            for (int m = 0; m < F; ++m) z[m] = b.x[u][(r * F + m) >> 2][(r * F + m) & 3];
+            for (int m = 0; m < F; ++m) z[m] = b.xe(u, r, m);
 #pragma unroll
-            for (int m = 0; m < P; ++m) z[F + m] = b.y[u][r * P + m];
+            for (int m = 0; m < P; ++m) z[F + m] = b.ye(u, r, m);
             small_row<F, P>(acc, z);
         }
     }
@@ -165,18 +121,18 @@ __global__ __launch_bounds__(BLOCK, (SmallCfg<F, P>::WPS)) void gram_small_kerne
     if (wave_id < nb) {
         // the clamped batch of an out-of-range fetch: loads stay unconditional and in bounds
         const long long spare = wave_id % nb;
-        SmallBuf<F, P> ba, bb;
-        small_fetch<F, P>(ba, X, Y, wave_id, lane);
+        wm_small::Buf<typename C::S> ba, bb;
+        wm_small::fetch<typename C::S>(ba, X, Y, wave_id, lane);
         // Two batches per trip, both consumed unconditionally (with the second consume under an
         // `if`, hipcc sinks that batch's loads into the branch and waits for them on the spot);
         // an odd last batch is consumed behind the loop.
         long long b = wave_id;
         for (; b + nwaves < nb; b += 2 * nwaves) {
-            small_fetch<F, P>(bb, X, Y, b + nwaves, lane);
+            wm_small::fetch<typename C::S>(bb, X, Y, b + nwaves, lane);
             __builtin_amdgcn_sched_barrier(0);
             small_consume<F, P>(ba, acc);
             __builtin_amdgcn_sched_barrier(0);
-            small_fetch<F, P>(ba, X, Y, b + 2 * nwaves < nb ? b + 2 * nwaves : spare, lane);
+            wm_small::fetch<typename C::S>(ba, X, Y, b + 2 * nwaves < nb ? b + 2 * nwaves : spare, lane);
             __builtin_amdgcn_sched_barrier(0);
             small_consume<F, P>(bb, acc);
             __builtin_amdgcn_sched_barrier(0);
@@ -241,12 +197,6 @@ __global__ __launch_bounds__(64) void gram_small_finalize_kernel(const double *_
     if (threadIdx.x == 0) acc[e] += s;
 }
 
-// the instantiated shapes: the reference family F = 2p, P = p (p = 1..5), one target with up to
-// eight predictors, and two odd shapes that take the R = 4 path with a multi-column Y
-#define WM_SMALL_SHAPES(X_)                                                                    \
-    X_(1, 1) X_(2, 1) X_(3, 1) X_(4, 1) X_(5, 1) X_(6, 1) X_(7, 1) X_(8, 1)                    \
-    X_(4, 2) X_(6, 3) X_(8, 4) X_(10, 5) X_(5, 2) X_(5, 3)
-
 int small_grid()
 {
     return wm_num_cus() * 2;     // at most 2 waves per SIMD (launch bounds): every workgroup is resident
@@ -258,8 +208,7 @@ bool wm_gram_small_supported(const float *X, const float *Y, int F, int P)
 {
 #define X_(F_, P_)                                                                             \
     if (F == F_ && P == P_)                                                                    \
-        return (((uintptr_t)X) & 15) == 0 &&                                                   \
-               (((uintptr_t)Y) & (SmallCfg<F_, P_>::YW * 4 - 1)) == 0;
+        return wm_small::aligned<SmallCfg<F_, P_>::S>(X, Y);
     WM_SMALL_SHAPES(X_)
 #undef X_
     return false;

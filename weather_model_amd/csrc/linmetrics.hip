@@ -14,30 +14,37 @@
 //   partials are per workgroup, float64, combined in a fixed order by metrics_finish_kernel and ADDED
 //   to sums[4] = {sum d^2, sum |d|, sum (log1p(max(pred,eps)) - log1p(max(y,eps)))^2, count}.
 #include "common.h"
+#include "small_stream.h"
 
 namespace {
 
 constexpr int BLOCK = 256;
 constexpr int LM_MAX_BETA = 4096;          // (F + 1) * PT doubles in LDS: 32 KB
 constexpr int LM_MAX_P = 32;
+constexpr float LM_CLAMP_HI = 1.0e37f;     // msle operands are clamped to [eps, 1e37]: 1 / (2 + a + b) stays a normal number
 
-// log1p(a) - log1p(b) = log1p(t), t = (a - b) / (1 + b), for a, b >= eps > 0 (so t > -1).  Near zero
-// the odd series 2 atanh(t / (2 + t)) (|t| <= 1/2: s <= 1/5, the s^11 term is below 2e-9 of the
-// result); elsewhere the hardware logarithm of 1 + t, which is then away from its zero.  ~20
-// instructions against ~150 for two library log1pf calls, which were 3/4 of this kernel's time;
-// the result is within ~3e-7 relative of the float64 value (keras' own float32 log(x + 1) is not).
+// log1p(a) - log1p(b) = log((1 + a) / (1 + b)) = 2 atanh(s), s = (a - b) / (2 + a + b), for
+// a, b in [eps, 1e37]: ONE reciprocal and the odd series (|s| <= 1/5: the s^11 term is below 1e-8 of
+// the result).  Beyond that -- the two values differ by a factor of 1.5 and more, which no lane of a
+// wave sees on a fitted model's rows -- the difference of the two hardware logarithms, which is then
+// at least 0.4 and takes the rounding of its terms (~1e-7 of each), under a branch the wave skips.
+// (Round 3, first version: log(1 + (a - b) / (1 + b)) computed beside the series for every output and
+// selected -- two reciprocals and a logarithm, 12 quarter-rate issue slots of ~45 -- and that form
+// returned 0 for b beyond 2^24 a.)  Within ~3e-7 relative of the float64 value for operands of order
+// one (keras' own float32 log(x + 1) is not).
 __device__ __forceinline__ float lm_log_ratio(float a, float b)
 {
-    const float t = (a - b) * __builtin_amdgcn_rcpf(1.0f + b);
-    const float s = t * __builtin_amdgcn_rcpf(2.0f + t);
+    const float u = a - b;
+    const float s = u * __builtin_amdgcn_rcpf((2.0f + a) + b);
     const float s2 = s * s;
     float poly = fmaf(s2, 1.0f / 9.0f, 1.0f / 7.0f);
     poly = fmaf(s2, poly, 1.0f / 5.0f);
     poly = fmaf(s2, poly, 1.0f / 3.0f);
     poly = fmaf(s2, poly, 1.0f);
-    const float near = 2.0f * s * poly;
-    const float far = __builtin_amdgcn_logf(1.0f + t) * 0.69314718055994530942f;
-    return fabsf(t) <= 0.5f ? near : far;
+    float r = (s + s) * poly;
+    if (__builtin_expect(!(fabsf(s) <= 0.2f), 0))
+        r = (__builtin_amdgcn_logf(1.0f + a) - __builtin_amdgcn_logf(1.0f + b)) * 0.69314718055994530942f;
+    return r;
 }
 
 __device__ __forceinline__ void lm_residual(float pred, float y, bool msle, float eps, double &sse,
@@ -47,8 +54,55 @@ __device__ __forceinline__ void lm_residual(float pred, float y, bool msle, floa
     sse = fma(d, d, sse);
     sae += fabs(d);
     if (msle) {
-        const float e = lm_log_ratio(fmaxf(pred, eps), fmaxf(y, eps));
+        const float e = lm_log_ratio(__builtin_amdgcn_fmed3f(pred, eps, LM_CLAMP_HI),
+                                     __builtin_amdgcn_fmed3f(y, eps, LM_CLAMP_HI));
         sle = fma((double)e, (double)e, sle);
+    }
+}
+
+// The residual sums of the N outputs of one row.  The rare far form is ONE branch behind all the
+// near forms: a branch per output makes hipcc sink each output's dot product down to its use, while
+// the scalar loads of beta stay at the top and are parked in VGPR lanes in between.
+template <int N, bool MSLE>
+__device__ __forceinline__ void lm_residuals(const float (&pred)[N], const float (&y)[N], float eps,
+                                             double &sse, double &sae, double &sle)
+{
+#pragma unroll
+    for (int p = 0; p < N; ++p) {
+        const double d = (double)pred[p] - (double)y[p];
+        sse = fma(d, d, sse);
+        sae += fabs(d);
+    }
+    if (MSLE) {
+        // clamped to [eps, 1e37] by one v_med3 each (fmaxf costs two instructions: it quiets its
+        // operand first), so 2 + a + b and its reciprocal stay normal numbers; values beyond 1e37 count as 1e37
+        float e[N];
+        bool far = false;
+#pragma unroll
+        for (int p = 0; p < N; ++p) {
+            const float a = __builtin_amdgcn_fmed3f(pred[p], eps, LM_CLAMP_HI);
+            const float b = __builtin_amdgcn_fmed3f(y[p], eps, LM_CLAMP_HI);
+            const float u = a - b;
+            const float s = u * __builtin_amdgcn_rcpf((2.0f + a) + b);
+            const float s2 = s * s;
+            float poly = fmaf(s2, 1.0f / 9.0f, 1.0f / 7.0f);
+            poly = fmaf(s2, poly, 1.0f / 5.0f);
+            poly = fmaf(s2, poly, 1.0f / 3.0f);
+            poly = fmaf(s2, poly, 1.0f);
+            e[p] = (s + s) * poly;
+            far |= !(fabsf(s) <= 0.2f);
+        }
+        if (__builtin_expect(far, 0)) {
+#pragma unroll
+            for (int p = 0; p < N; ++p)
+                e[p] = lm_log_ratio(__builtin_amdgcn_fmed3f(pred[p], eps, LM_CLAMP_HI),
+                                    __builtin_amdgcn_fmed3f(y[p], eps, LM_CLAMP_HI));
+        }
+        // the squares of a group (N <= 16 terms of similar size) in float32, one float64 add per group
+        float q = 0.f;
+#pragma unroll
+        for (int p = 0; p < N; ++p) q = fmaf(e[p], e[p], q);
+        sle += (double)q;
     }
 }
 
@@ -123,6 +177,133 @@ __global__ __launch_bounds__(BLOCK) void linear_metrics_kernel(const float *__re
 #pragma unroll
         for (int p = 0; p < PT; ++p)
             if (p < P) lm_residual((float)s[p], yr[p], msle != 0, eps, sse, sae, sle);
+    }
+    lm_block_out(sse, sae, sle, partial);
+}
+
+// Narrow rows (F + P <= 15: the reference's own multipleRegression fit is F = 2, P = 1).  The direct
+// kernel above keeps ONE row per lane in flight and waits for X, then for Y (F=2, P=1: 4.2 TB/s).
+// This one is gram_small_kernel's memory side (small_stream.h): a lane owns R consecutive rows of each
+// of U steps, 16-byte non-temporal loads, batches dealt round-robin to the waves, the next batch's
+// loads issued before the current batch's arithmetic.  beta sits in SGPRs (scalar loads at
+// uniform addresses); the float64 dot products run in the direct kernel's order (intercept first,
+// then features in order), so the predictions are the same bits.
+template <int F, int P>
+struct LmSmallCfg {
+    static constexpr int M = F + P;
+    static constexpr int R0 = (F % 4 == 0) ? 1 : ((F % 2 == 0) ? 2 : 4);
+    static constexpr int U0 = 48 / (R0 * M);
+    static constexpr int U = U0 < 1 ? 1 : (U0 > 8 ? 8 : U0);
+    using S = wm_small::Stream<F, P, U>;
+};
+
+// float32 prediction of one row: float64 dot product, intercept first, then the features in order
+template <int F, int P>
+__device__ __forceinline__ void lm_small_predict(const float (&x)[F], const double *__restrict__ bt,
+                                                 float *__restrict__ pred)
+{
+    double s[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) s[p] = bt[F * P + p];
+#pragma unroll
+    for (int m = 0; m < F; ++m) {
+        const double xd = (double)x[m];
+#pragma unroll
+        for (int p = 0; p < P; ++p) s[p] = fma(xd, bt[m * P + p], s[p]);
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) pred[p] = (float)s[p];
+}
+
+template <int F, int P, bool MSLE>
+__device__ __forceinline__ void lm_small_row(const float (&x)[F], const float (&y)[P],
+                                             const double *__restrict__ bt, float eps, double &sse,
+                                             double &sae, double &sle)
+{
+    float pred[P];
+    lm_small_predict<F, P>(x, bt, pred);
+    lm_residuals<P, MSLE>(pred, y, eps, sse, sae, sle);
+}
+
+// A batch: the predictions of all its rows first, then the residual sums of groups of up to 8
+// outputs -- one (rare) far branch per group instead of one per row, so that the rows' dependent
+// chains (reciprocal, series, float64 square) overlap.
+template <int F, int P, bool MSLE>
+__device__ __forceinline__ void lm_small_consume(const wm_small::Buf<typename LmSmallCfg<F, P>::S> &b,
+                                                 const double *__restrict__ bt, float eps,
+                                                 double &sse, double &sae, double &sle)
+{
+    using S = typename LmSmallCfg<F, P>::S;
+    // beta beyond ~40 doubles does not fit the SGPR file beside the rest: an opaque offset per batch
+    // (the pointer must stay the kernel argument, or the loads turn into flat vector loads) keeps
+    // the scalar loads next to their use instead of hoisted and spilled
+    if constexpr ((F + 1) * P > 40) {
+        int zero = 0;
+        asm volatile("" : "+s"(zero));
+        bt += zero;
+    }
+    constexpr int ROWS = S::U * S::R;                       // rows of the lane in a batch
+    constexpr int G0 = 8 / P < 1 ? 1 : 8 / P;               // rows per residual group
+    constexpr int G = G0 > ROWS ? ROWS : G0;
+#pragma unroll
+    for (int g0 = 0; g0 < ROWS; g0 += G) {
+        constexpr int GP = G * P;
+        float pred[GP], y[GP];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int q = g0 + g < ROWS ? g0 + g : ROWS - 1;     // ROWS % G != 0: the last row again ...
+            const int u = q / S::R, r = q % S::R;
+            float x[F];
+#pragma unroll
+            for (int m = 0; m < F; ++m) x[m] = b.xe(u, r, m);
+            lm_small_predict<F, P>(x, bt, pred + g * P);
+#pragma unroll
+            for (int m = 0; m < P; ++m) y[g * P + m] = g0 + g < ROWS ? b.ye(u, r, m) : pred[g * P + m];   // ... with a zero residual
+        }
+        lm_residuals<GP, MSLE>(pred, y, eps, sse, sae, sle);
+    }
+}
+
+template <int F, int P, bool MSLE>
+__global__ __launch_bounds__(BLOCK, 2) void linear_metrics_small_kernel(
+    const float *__restrict__ X, const float *__restrict__ Y, const double *__restrict__ beta, long long n,
+    float eps, double *__restrict__ partial)
+{
+    using S = typename LmSmallCfg<F, P>::S;
+    const int lane = threadIdx.x & 63;
+    const long long nwaves = (long long)gridDim.x * (BLOCK / 64);
+    const long long wave_id = (long long)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    const double *__restrict__ bt = beta;      // uniform addresses: scalar loads, hoisted when they fit
+    double sse = 0.0, sae = 0.0, sle = 0.0;
+    const long long nb = n / S::ROWS_BATCH;
+    if (wave_id < nb) {
+        const long long spare = wave_id % nb;          // the clamped batch of an out-of-range fetch
+        wm_small::Buf<S> ba, bb;
+        wm_small::fetch<S>(ba, X, Y, wave_id, lane);
+        long long b = wave_id;
+        for (; b + nwaves < nb; b += 2 * nwaves) {
+            wm_small::fetch<S>(bb, X, Y, b + nwaves, lane);
+            __builtin_amdgcn_sched_barrier(0);
+            lm_small_consume<F, P, MSLE>(ba, bt, eps, sse, sae, sle);
+            __builtin_amdgcn_sched_barrier(0);
+            wm_small::fetch<S>(ba, X, Y, b + 2 * nwaves < nb ? b + 2 * nwaves : spare, lane);
+            __builtin_amdgcn_sched_barrier(0);
+            lm_small_consume<F, P, MSLE>(bb, bt, eps, sse, sae, sle);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (b < nb) lm_small_consume<F, P, MSLE>(ba, bt, eps, sse, sae, sle);
+    }
+    // the rows behind the last full batch (fewer than ROWS_BATCH): one row per lane
+    for (long long r0 = nb * S::ROWS_BATCH + wave_id * 64; r0 < n; r0 += nwaves * 64) {
+        const long long row = r0 + lane;
+        if (row < n) {
+            float x[F], y[P];
+#pragma unroll
+            for (int m = 0; m < F; ++m) x[m] = X[row * F + m];
+#pragma unroll
+            for (int m = 0; m < P; ++m) y[m] = Y[row * P + m];
+            lm_small_row<F, P, MSLE>(x, y, bt, eps, sse, sae, sle);
+        }
     }
     lm_block_out(sse, sae, sle, partial);
 }
@@ -247,6 +428,155 @@ __global__ __launch_bounds__(BLOCK) void linear_metrics_staged_kernel(
     lm_block_out(sse, sae, sle, partial);
 }
 
+// The staged kernel with F = 4 QX and P compile-time constants and the NEXT tile's global loads in
+// flight while this tile is computed (the staged kernel above loads, waits, computes: with five
+// waves per SIMD and ~1300 cycles of arithmetic per tile the loads' latency was not covered).  A
+// lane's pieces of a tile (16 bytes at q = lane + 64 k) always land at the same LDS offsets, so those
+// are computed once.  beta comes by scalar loads at compile-time offsets.  Y rows that are not whole
+// 16-byte pieces are read by their own lane (8-byte loads for even P).
+// (P = 10 and 12 were tried: rows of beta that are not 8 or 16 doubles fragment the SGPR file, 285-425
+// spilled SGPRs, 5.1 ms against the staged kernel's 2.75 at F=20, P=10 -- those stay there.)
+#define WM_LM_TILE_SHAPES(X_) X_(4, 8) X_(3, 6) X_(8, 16) X_(4, 4) X_(2, 8)
+
+template <int QX, int P>
+struct LmTile {
+    static constexpr int F = 4 * QX;
+    static constexpr bool VECY = P % 4 == 0;
+    static constexpr int QY = VECY ? P / 4 : 0;
+    static constexpr int XSTRIDE = 4 * F + 16, YSTRIDE = 4 * P + 16;          // bytes between LDS rows
+    static constexpr int WAVE_BYTES = 64 * XSTRIDE + (VECY ? 64 * YSTRIDE : 0);
+    static constexpr int YN = VECY ? 1 : P;
+    f32x4 x[QX];
+    f32x4 y4[VECY ? QY : 1];
+    float y1[YN];
+};
+
+template <int QX, int P>
+__device__ __forceinline__ void lm_tile_load(LmTile<QX, P> &tl, const float *__restrict__ X,
+                                             const float *__restrict__ Y, long long t, long long n,
+                                             int lane)
+{
+    using T = LmTile<QX, P>;
+    const long long row0 = t << 6;
+    const int rows = (int)(n - row0 < 64 ? n - row0 : 64);
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(X + row0 * T::F);
+    const int last = rows * QX - 1;
+#pragma unroll
+    for (int k = 0; k < QX; ++k) {
+        const int q = lane + 64 * k;
+        tl.x[k] = __builtin_nontemporal_load(src + (q < last ? q : last));
+    }
+    if constexpr (T::VECY) {
+        const f32x4 *ysrc = reinterpret_cast<const f32x4 *>(Y + row0 * P);
+        const int ylast = rows * T::QY - 1;
+#pragma unroll
+        for (int k = 0; k < T::QY; ++k) {
+            const int q = lane + 64 * k;
+            tl.y4[k] = __builtin_nontemporal_load(ysrc + (q < ylast ? q : ylast));
+        }
+    } else {
+        const float *yr = Y + (row0 + (lane < rows ? lane : rows - 1)) * P;
+        if constexpr (P % 2 == 0) {
+#pragma unroll
+            for (int j = 0; j < P / 2; ++j) {
+                const f2u v = __builtin_nontemporal_load(reinterpret_cast<const f2u *>(yr) + j);
+                tl.y1[2 * j] = v[0];
+                tl.y1[2 * j + 1] = v[1];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < P; ++j) tl.y1[j] = __builtin_nontemporal_load(yr + j);
+        }
+    }
+}
+
+template <int QX, int P, bool MSLE>
+__global__ __launch_bounds__(BLOCK) void linear_metrics_tile_kernel(
+    const float *__restrict__ X, const float *__restrict__ Y, const double *__restrict__ beta, long long n,
+    float eps, double *__restrict__ partial)
+{
+    using T = LmTile<QX, P>;
+    constexpr int F = T::F;
+    extern __shared__ __align__(16) char lds[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    char *xs = lds + wv * T::WAVE_BYTES;
+    char *ys = xs + 64 * T::XSTRIDE;
+    int offx[QX], offy[T::VECY ? T::QY : 1];
+#pragma unroll
+    for (int k = 0; k < QX; ++k) {
+        const int q = lane + 64 * k;
+        offx[k] = (q / QX) * T::XSTRIDE + (q % QX) * 16;
+    }
+    if constexpr (T::VECY) {
+#pragma unroll
+        for (int k = 0; k < T::QY; ++k) {
+            const int q = lane + 64 * k;
+            offy[k] = (q / T::QY) * T::YSTRIDE + (q % T::QY) * 16;
+        }
+    }
+    const char *xrow = xs + lane * T::XSTRIDE;
+    const char *yrow = ys + lane * T::YSTRIDE;
+    double sse = 0.0, sae = 0.0, sle = 0.0;
+    const long long tiles = (n + 63) >> 6;
+    const long long stride = (long long)gridDim.x * (BLOCK / 64);
+    long long t = (long long)blockIdx.x * (BLOCK / 64) + wv;
+    T cur;
+    if (t < tiles) lm_tile_load<QX, P>(cur, X, Y, t, n, lane);
+    for (; t < tiles; t += stride) {
+        const long long row0 = t << 6;
+        const int rows = (int)(n - row0 < 64 ? n - row0 : 64);
+#pragma unroll
+        for (int k = 0; k < QX; ++k) *reinterpret_cast<f32x4 *>(xs + offx[k]) = cur.x[k];
+        float yv[P];
+        if constexpr (T::VECY) {
+#pragma unroll
+            for (int k = 0; k < T::QY; ++k) *reinterpret_cast<f32x4 *>(ys + offy[k]) = cur.y4[k];
+        } else {
+#pragma unroll
+            for (int j = 0; j < P; ++j) yv[j] = cur.y1[j];
+        }
+        __builtin_amdgcn_wave_barrier();
+        // the next tile of this wave (its own again behind the last: in bounds, never used)
+        lm_tile_load<QX, P>(cur, X, Y, t + stride < tiles ? t + stride : t, n, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        // (F + 1) P doubles do not fit the SGPR file: left to itself hipcc hoists all the loads out
+        // of the tile loop and parks them in VGPR lanes (477 v_readlane per tile at F=16, P=8); an opaque
+        // offset (the pointer itself must stay the kernel argument, or the loads turn into flat
+        // vector loads) per tile keeps them scalar loads next to their use
+        int zero = 0;
+        asm volatile("" : "+s"(zero));
+        const double *__restrict__ bp = beta + zero;
+        double s[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) s[p] = bp[F * P + p];
+#pragma unroll
+        for (int f0 = 0; f0 < F; f0 += 4) {
+            const f32x4 x = *reinterpret_cast<const f32x4 *>(xrow + f0 * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double xd = (double)x[j];
+#pragma unroll
+                for (int p = 0; p < P; ++p) s[p] = fma(xd, bp[(f0 + j) * P + p], s[p]);
+            }
+        }
+        if constexpr (T::VECY) {
+#pragma unroll
+            for (int k = 0; k < T::QY; ++k) {
+                const f32x4 y = *reinterpret_cast<const f32x4 *>(yrow + k * 16);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) yv[4 * k + j] = y[j];
+            }
+        }
+        float pred[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) pred[p] = (float)s[p];
+        if (lane < rows) lm_residuals<P, MSLE>(pred, yv, eps, sse, sae, sle);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_wave_barrier();
+    }
+    lm_block_out(sse, sae, sle, partial);
+}
+
 __global__ __launch_bounds__(BLOCK) void residual_sums_kernel(const float *__restrict__ pred,
                                                              const float *__restrict__ Y,
                                                              long long count, int msle, float eps,
@@ -282,6 +612,12 @@ int lm_pt(int P) { return P <= 1 ? 1 : P <= 2 ? 2 : P <= 4 ? 4 : P <= 6 ? 6 : P 
 bool lm_direct_forced()                    // probe switch: WM_LINMETRICS_DIRECT=1 keeps the lane-per-row loads
 {
     static const bool v = [] { const char *e = getenv("WM_LINMETRICS_DIRECT"); return e && e[0] == '1'; }();
+    return v;
+}
+
+bool lm_untiled_forced()                   // probe switch: WM_LINMETRICS_TILE=0 keeps the round-3a staged kernel
+{
+    static const bool v = [] { const char *e = getenv("WM_LINMETRICS_TILE"); return e && e[0] == '0'; }();
     return v;
 }
 
@@ -329,8 +665,47 @@ extern "C" int wm_linear_metrics_f32(const float *X, const float *Y, const doubl
         beta_bytes + (size_t)(BLOCK / 64) * 64 * ((4 * F + 16) + (vecy ? 4 * P + 16 : 0));
     const bool staged = vec && F >= 8 && staged_lds <= 64 * 1024 && !lm_direct_forced();
     double *partial = (double *)workspace;
-    int grid;
-    if (staged) {
+    int grid = 0;
+    bool small = false;
+    if (!lm_direct_forced()) {
+#define X_(F_, P_)                                                                             \
+    if (F == F_ && P == P_ && wm_small::aligned<LmSmallCfg<F_, P_>::S>(X, Y)) {                \
+        grid = wm_num_cus() * 2;             /* 2 waves per SIMD (launch bounds): all resident */ \
+        if (want_msle)                                                                         \
+            hipLaunchKernelGGL((linear_metrics_small_kernel<F_, P_, true>), dim3(grid), dim3(BLOCK), 0, \
+                               st, X, Y, beta, (long long)n, msle_eps, partial);               \
+        else                                                                                   \
+            hipLaunchKernelGGL((linear_metrics_small_kernel<F_, P_, false>), dim3(grid), dim3(BLOCK), 0, \
+                               st, X, Y, beta, (long long)n, msle_eps, partial);               \
+        small = true;                                                                          \
+    }
+        WM_SMALL_SHAPES(X_)
+#undef X_
+    }
+    bool tiled = false;
+    if (!small && !lm_direct_forced() && !lm_untiled_forced() && (((uintptr_t)X) & 15) == 0) {
+#define X_(QX_, P_)                                                                            \
+    if (F == 4 * QX_ && P == P_ && (!LmTile<QX_, P_>::VECY || (((uintptr_t)Y) & 15) == 0)) {   \
+        const long long want = ((n + 63) / 64 + BLOCK / 64 - 1) / (BLOCK / 64);                \
+        const long long cap = (long long)wm_num_cus() * 8;                                     \
+        grid = (int)(want < cap ? want : cap);                                                 \
+        const size_t lds = (size_t)(BLOCK / 64) * LmTile<QX_, P_>::WAVE_BYTES;                 \
+        if (want_msle)                                                                         \
+            hipLaunchKernelGGL((linear_metrics_tile_kernel<QX_, P_, true>), dim3(grid), dim3(BLOCK), \
+                               lds, st, X, Y, beta, (long long)n, msle_eps, partial);          \
+        else                                                                                   \
+            hipLaunchKernelGGL((linear_metrics_tile_kernel<QX_, P_, false>), dim3(grid), dim3(BLOCK), \
+                               lds, st, X, Y, beta, (long long)n, msle_eps, partial);          \
+        tiled = true;                                                                          \
+    }
+        WM_LM_TILE_SHAPES(X_)
+#undef X_
+    }
+    if (small) {
+        WM_LAUNCH_CHECK("linear_metrics_small_kernel");
+    } else if (tiled) {
+        WM_LAUNCH_CHECK("linear_metrics_tile_kernel");
+    } else if (staged) {
         const long long tiles = (n + 63) / 64;
         const long long want = (tiles + BLOCK / 64 - 1) / (BLOCK / 64);
         const long long cap = (long long)wm_num_cus() * 8;
