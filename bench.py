@@ -468,8 +468,11 @@ def run_gram(F, n_rows, steps, warmup, rank, world, cpu_base, P=1, dist="uniform
         torch.cuda.synchronize()
         mms = float(np.mean([a.elapsed_time(c) for a, c in mev]))
         fused = bool(L.wm_linear_metrics_supported(F, P))
+        wide = not fused and bool(L.wm_linear_metrics_wide_supported(F, P))
         mkey = {(16, 8): "linear_metrics_tile_kernel<4, 8, true>",
-                (2, 1): "linear_metrics_small_kernel<2, 1, true>"}.get((F, P), "residual_sums_kernel")
+                (2, 1): "linear_metrics_small_kernel<2, 1, true>"}.get(
+                    (F, P), "linear_metrics_wide_kernel<14, true, true, false, false>" if wide
+                    else "residual_sums_kernel")
         mgbs = bytes_per_row * n_rows / mms / 1e6
         res["fit_metrics"] = {
             "ms": mms, "mse": float(sums[0] / sums[3]), "mae": float(sums[1] / sums[3]),
@@ -484,8 +487,11 @@ def run_gram(F, n_rows, steps, warmup, rank, world, cpu_base, P=1, dist="uniform
                          "frac": 2.0 * F * P * n_rows / mms / 1e9 / MFMA_F32_PEAK_TF,
                          "traffic": pmc_traffic([mkey], default_shape),
                          "traffic_source": pmc_source([mkey], default_shape),
-                         "traffic_note": "residual_sums_kernel only (the GEMM is the library's)",
-                         "kernel": "library GEMM (predictions) + residual_sums_kernel",
+                         **({"kernel": mkey + " (predictions on the fp32 MFMA, scored from the "
+                                              "accumulators; round 3a: library GEMM + residual pass)"}
+                            if wide else
+                            {"traffic_note": "residual_sums_kernel only (the GEMM is the library's)",
+                             "kernel": "library GEMM (predictions) + residual_sums_kernel"}),
                          "algorithmic_flops_per_row": 2 * F * P}}
     if cpu_base and rank == 0 and world == 1:
         res.update(gram_cpu_baselines(X, Y, F, P, beta))

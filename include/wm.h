@@ -405,6 +405,22 @@ int wm_residual_sums_f32(const float *pred, const float *Y, int64_t count, int w
                          float msle_eps, double *sums, void *workspace, size_t workspace_bytes,
                          void *stream);
 
+/* The same sums, and / or model.predict, for WIDE linear maps -- the reference's singleRegression
+ * model is Dense(432, linear) -> Dense(216) on 6^3 cubes (singleRegression.py:21,33,74-85; predict
+ * :579; loss and metrics :90-94, evaluated by fit :500-509): F % 4 == 0, P % 4 == 0, P <= 224,
+ * F <= 8192 (wm_linear_metrics_wide_supported).  pred = [X | 1] beta is formed on the fp32 MFMA
+ * (beta rounded to float32, float32 accumulation -- the arithmetic of the reference's own Dense
+ * layers) and, straight from the accumulators,
+ *   scored against Y into sums[4] as wm_linear_metrics_f32 does, when sums != NULL, and / or
+ *   written to Yhat (n x P float32), when Yhat != NULL  (Y may be NULL when sums is).
+ * X, Y, Yhat and workspace must be 16-byte aligned.  The workspace holds the per-workgroup float64
+ * partials and the float32 coefficient panels packed for the kernel (rebuilt by every call). */
+int wm_linear_metrics_wide_supported(int F, int P);
+size_t wm_linear_metrics_wide_workspace_bytes(int F, int P);
+int wm_linear_metrics_wide_f32(const float *X, const float *Y, const double *beta, int64_t n, int F,
+                               int P, int want_msle, float msle_eps, double *sums, float *Yhat,
+                               void *workspace, size_t workspace_bytes, void *stream);
+
 /* ------------------------------------------------------------------ exchange step ------- */
 
 /* The one collective of the data-parallel path (SURVEY.md 8b ABI block, 8e) for hosts without

@@ -436,6 +436,60 @@ def test_linear_metrics_stream_kernels_tails_and_far_branch(F, P):
                 np.testing.assert_allclose(off, got, rtol=3e-6, atol=1e-12)
 
 
+@pytest.mark.parametrize("F,P", [(432, 216), (20, 8), (64, 64), (100, 128), (36, 220), (16, 4), (48, 36)],
+                         ids=lambda v: str(v))
+def test_linear_wide_mfma_metrics_and_predict(F, P):
+    """wm_linear_metrics_wide_f32 (the reference's singleRegression map 432 -> 216,
+    singleRegression.py:74-85, and every panel width 4 / 8 / 14 tiles): predictions from the fp32
+    MFMA accumulators against a float64 product (float32 products and sums: 2e-5 of the largest
+    prediction), residual sums against a float64 restatement on those float32 predictions' float64
+    twins (2e-4: the predictions differ in their last bits), for row counts around the 32-row wave
+    tile and the 128-row workgroup pass and for F that is not a multiple of the 16-index stage;
+    predictions written and scored in one call equal the two separate calls bit for bit; targets far
+    from the predictions exercise the repeat pass."""
+    from weather_model_amd import ops
+    rng = np.random.default_rng(F + P)
+    beta = rng.uniform(-0.5, 0.5, (F + 1, P)) / np.sqrt(F)
+    beta[F] = rng.uniform(0.5, 1.5, P)
+    bd = torch.from_numpy(beta).cuda()
+    eps = np.float32(1e-7)
+    for n in (1, 31, 32, 33, 127, 128, 129, 1000, 20_011):
+        X = rng.uniform(0.0, 1.0, (n, F)).astype(np.float32)
+        ref = X.astype(np.float64) @ beta[:F] + beta[F]
+        Y = (ref + rng.normal(0, 0.05, (n, P))).astype(np.float32)
+        if n in (129, 1000):
+            # targets far from the predictions (and below eps): the wave raises the flag and the
+            # repeat pass replaces the msle sum with the one that has both forms
+            far = rng.uniform(size=Y.shape) < (0.2 if n == 129 else 0.001)
+            Y[far] = rng.uniform(-0.5, 9.0, int(far.sum())).astype(np.float32)
+        Xd, Yd = torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda()
+        _, pred = ops.linear_wide(Xd, bd, predict=True)
+        pn = pred.cpu().numpy().astype(np.float64)
+        assert np.abs(pn - ref).max() <= 2e-5 * np.abs(ref).max(), (F, P, n)
+        d = ref - Y
+        e = np.log1p(np.maximum(ref, eps)) - np.log1p(np.maximum(Y.astype(np.float64), eps))
+        for msle in (True, False):
+            want = np.array([(d * d).sum(), np.abs(d).sum(), (e * e).sum() if msle else 0.0, n * P])
+            sums = torch.zeros(4, device="cuda", dtype=torch.float64)
+            ops.linear_wide(Xd, bd, Yd, sums, want_msle=msle)
+            got = sums.cpu().numpy()
+            assert got[3] == want[3]
+            np.testing.assert_allclose(got[:3], want[:3], rtol=2e-4, atol=1e-12, err_msg=f"{F},{P},{n},{msle}")
+            both = torch.zeros(4, device="cuda", dtype=torch.float64)
+            _, p2 = ops.linear_wide(Xd, bd, Yd, both, want_msle=msle, predict=True)
+            assert torch.equal(p2, pred) and torch.equal(both, sums)
+    # what the drop-ins call: ops.linear_metrics / ops.linear_predict route wide maps here
+    if F * P >= 4096:
+        assert torch.equal(ops.linear_predict(Xd, bd), pred)
+    if not _lib_supported(F, P):
+        assert torch.equal(ops.linear_metrics(Xd, Yd, bd, want_msle=False), sums)
+
+
+def _lib_supported(F, P):
+    from weather_model_amd import _lib
+    return bool(_lib.lib().wm_linear_metrics_supported(F, P))
+
+
 def test_linear_metrics_rejects_bad_shapes():
     from weather_model_amd import ops
     X = torch.zeros((10, 4), device="cuda")

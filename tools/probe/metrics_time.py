@@ -14,8 +14,14 @@ def old(X, Y, beta):
 for spec in sys.argv[1:] or ["2:1:40000000", "16:8:40000000", "12:6:40000000", "32:1:20000000", "432:216:400000"]:
     F, P, n = (int(v) for v in spec.split(":"))
     X = ops.synth_uniform((n, F), seed=1)
-    Y = ops.synth_uniform((n, P), seed=2)
-    beta = torch.rand((F + 1, P), device="cuda", dtype=torch.float64) - 0.5
+    # a fitted model's rows: Y = [X | 1] beta + small noise (targets unrelated to the predictions
+    # would put every output on the rare far form of the msle term)
+    beta = (torch.rand((F + 1, P), device="cuda", dtype=torch.float64) - 0.5) / F ** 0.5
+    beta[F] += 1.0
+    Y = ops.synth_uniform((n, P), seed=2, lo=-0.02, hi=0.02)
+    step = max(1, 200_000_000 // (F + P))
+    for a in range(0, n, step):
+        Y[a:a + step] += (X[a:a + step].double() @ beta[:F] + beta[F]).float()
     for name, fn in (("fused", lambda: ops.linear_metrics(X, Y, beta)),
                      ("nomsle", lambda: ops.linear_metrics(X, Y, beta, want_msle=False)), ("old", lambda: old(X, Y, beta)),
                      ("gram", lambda: ops.gram(X, Y))):

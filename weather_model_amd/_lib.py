@@ -48,6 +48,9 @@ SIGNATURES = {
     "wm_linear_metrics_supported": (c_int, [c_int, c_int]),
     "wm_linear_metrics_f32": (c_int, [vp, vp, vp, c_i64, c_int, c_int, c_int, c_f32, vp, vp, c_sz, vp]),
     "wm_residual_sums_f32": (c_int, [vp, vp, c_i64, c_int, c_f32, vp, vp, c_sz, vp]),
+    "wm_linear_metrics_wide_supported": (c_int, [c_int, c_int]),
+    "wm_linear_metrics_wide_workspace_bytes": (c_sz, [c_int, c_int]),
+    "wm_linear_metrics_wide_f32": (c_int, [vp, vp, vp, c_i64, c_int, c_int, c_int, c_f32, vp, vp, vp, c_sz, vp]),
     "wm_model_param_count": (c_int, []),
     "wm_model_fwd_f32": (c_int, [vp, vp, vp, c_i64, vp]),
     "wm_model_workspace_bytes": (c_sz, [c_i64]),

@@ -77,7 +77,7 @@ __device__ __forceinline__ void lm_residuals(const float (&pred)[N], const float
         // clamped to [eps, 1e37] by one v_med3 each (fmaxf costs two instructions: it quiets its
         // operand first), so 2 + a + b and its reciprocal stay normal numbers; values beyond 1e37 count as 1e37
         float e[N];
-        bool far = false;
+        float smax = 0.f;                           // one v_max per output instead of a flag each
 #pragma unroll
         for (int p = 0; p < N; ++p) {
             const float a = __builtin_amdgcn_fmed3f(pred[p], eps, LM_CLAMP_HI);
@@ -90,9 +90,9 @@ __device__ __forceinline__ void lm_residuals(const float (&pred)[N], const float
             poly = fmaf(s2, poly, 1.0f / 3.0f);
             poly = fmaf(s2, poly, 1.0f);
             e[p] = (s + s) * poly;
-            far |= !(fabsf(s) <= 0.2f);
+            smax = __builtin_fmaxf(smax, fabsf(s));
         }
-        if (__builtin_expect(far, 0)) {
+        if (__builtin_expect(!(smax <= 0.2f), 0)) {
 #pragma unroll
             for (int p = 0; p < N; ++p)
                 e[p] = lm_log_ratio(__builtin_amdgcn_fmed3f(pred[p], eps, LM_CLAMP_HI),
@@ -106,7 +106,53 @@ __device__ __forceinline__ void lm_residuals(const float (&pred)[N], const float
     }
 }
 
-__device__ __forceinline__ void lm_block_out(double sse, double sae, double sle, double *partial)
+// Four outputs of one MFMA accumulator: the near form summed into sq for every output, smax = the
+// largest |s| met (beyond 1/5 one of them needs the other form; lm_far4 then returns the sum of the
+// four squares in full).
+template <bool MSLE>
+__device__ __forceinline__ void lm_residuals_near4(const f32x4 pred, const f32x4 y, float eps,
+                                                   double &sse, double &sae, float &sq, float &smax)
+{
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const double d = (double)pred[p] - (double)y[p];
+        sse = fma(d, d, sse);
+        sae += fabs(d);
+    }
+    if (MSLE) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const float a = __builtin_amdgcn_fmed3f(pred[p], eps, LM_CLAMP_HI);
+            const float b = __builtin_amdgcn_fmed3f(y[p], eps, LM_CLAMP_HI);
+            const float s = (a - b) * __builtin_amdgcn_rcpf((2.0f + a) + b);
+            const float s2 = s * s;
+            float poly = fmaf(s2, 1.0f / 9.0f, 1.0f / 7.0f);
+            poly = fmaf(s2, poly, 1.0f / 5.0f);
+            poly = fmaf(s2, poly, 1.0f / 3.0f);
+            poly = fmaf(s2, poly, 1.0f);
+            const float e = (s + s) * poly;
+            sq = fmaf(e, e, sq);
+            smax = __builtin_fmaxf(smax, fabsf(s));          // one v_max per output; a flag per output
+        }                                                    // became compare + select + 16-bit or
+    }
+}
+
+// Both forms computed and selected, no branch: for the repeat pass of the wide kernel.
+__device__ __forceinline__ float lm_log_ratio_select(float a, float b)
+{
+    const float s = (a - b) * __builtin_amdgcn_rcpf((2.0f + a) + b);
+    const float s2 = s * s;
+    float poly = fmaf(s2, 1.0f / 9.0f, 1.0f / 7.0f);
+    poly = fmaf(s2, poly, 1.0f / 5.0f);
+    poly = fmaf(s2, poly, 1.0f / 3.0f);
+    poly = fmaf(s2, poly, 1.0f);
+    const float near = (s + s) * poly;
+    const float far = (__builtin_amdgcn_logf(1.0f + a) - __builtin_amdgcn_logf(1.0f + b)) * 0.69314718055994530942f;
+    return fabsf(s) <= 0.2f ? near : far;
+}
+
+__device__ __forceinline__ void lm_block_out(double sse, double sae, double sle, double *partial,
+                                             bool only_sle = false)
 {
     __shared__ double red[BLOCK / 64][3];
     sse = wave_sum(sse);
@@ -115,7 +161,7 @@ __device__ __forceinline__ void lm_block_out(double sse, double sae, double sle,
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (lane == 0) { red[wv][0] = sse; red[wv][1] = sae; red[wv][2] = sle; }
     __syncthreads();
-    if (threadIdx.x < 3) {
+    if (threadIdx.x < 3 && (!only_sle || threadIdx.x == 2)) {
         double s = 0.0;
         for (int w = 0; w < BLOCK / 64; ++w) s += red[w][threadIdx.x];
         partial[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = s;       // entry-major
@@ -577,6 +623,193 @@ __global__ __launch_bounds__(BLOCK) void linear_metrics_tile_kernel(
     lm_block_out(sse, sae, sle, partial);
 }
 
+// ---- wide shapes (the reference's singleRegression fit is F = 432, P = 216: singleRegression.py:21,33,
+// 74-85): (F + 1) P coefficients do not fit registers or the scalar cache, and 2 F P flop per row is
+// MFMA work (186 624 flop against 2 592 bytes).  Until now the predictions were a library GEMM into a
+// buffer that wm_residual_sums_f32 then read back.  Here they are formed on v_mfma_f32_16x16x4_f32 and
+// scored (and / or written) from the accumulators:
+//   D[n][m] = sum_k beta[k][n] X[m][k]: A = beta^T from LDS, B = X straight from global memory.  An
+//   MFMA contracts over the lane group g and nothing fixes which four indices a step takes: lane
+//   (i, g) reads 16 bytes -- indices 16 kb + 4 g .. + 3 -- of X row m0 + i and of beta^T row n0 + i, and
+//   step r uses element r of both.  beta is packed once per call as float32 [kb][n][16] (zero beyond
+//   F and P), one 16-index stage (NT x 1 KiB) per barrier, double-buffered; a wave owns 32 rows and
+//   ALL NT output tiles (NT x 2 accumulators), so X is read exactly once and a lane ends with four
+//   consecutive outputs of a row per accumulator: 16-byte loads of Y / stores of the predictions.
+// Predictions on this path are float32 sums of float32 products (beta rounded to float32), like the
+// library GEMM's and the reference's own Dense layers.
+constexpr int LW_MT = 2;                               // 16-row tiles per wave
+constexpr int LW_ROWS = (BLOCK / 64) * LW_MT * 16;     // rows per workgroup pass
+
+__global__ __launch_bounds__(BLOCK) void lw_pack_kernel(const double *__restrict__ beta, int F, int P,
+                                                        int NT, int KBn, float *__restrict__ packed,
+                                                        int *__restrict__ far_flag)
+{
+    const int N = NT * 16;
+    const long long total = (long long)KBn * N * 16;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *far_flag = 0;
+    for (long long e = (long long)blockIdx.x * BLOCK + threadIdx.x; e < total + N;
+         e += (long long)gridDim.x * BLOCK) {
+        if (e < total) {
+            const int kk = (int)(e & 15);
+            const int n = (int)((e >> 4) % N);
+            const int k = (int)((e >> 4) / N) * 16 + kk;
+            packed[e] = (k < F && n < P) ? (float)beta[(size_t)k * P + n] : 0.0f;
+        } else {
+            const int n = (int)(e - total);
+            packed[e] = n < P ? (float)beta[(size_t)F * P + n] : 0.0f;        // the intercept row
+        }
+    }
+}
+
+// REDO: the repeat pass.  The first pass sums the near form of the msle term for every output, no
+// branch, and raises *far_flag when an output needed the far form (a per-step branch or call for
+// the rare case cost 100-340 spilled VGPRs at NT = 14 and 0.5 of 2.26 ms per 1e6 rows); the repeat
+// pass -- same grid, launched behind it, every workgroup leaving at once unless the flag is up --
+// forms the predictions again, computes both forms for every output and replaces the msle partials.
+// (Starting the second workgroup of every CU half a pass late, so that one's epilogue runs beside the
+// other's MFMA phase, measured 1.91-1.97 against 1.96-2.05 ms: within the run-to-run spread, left out.)
+template <int NT, bool MSLE, bool RESID, bool WRITE, bool REDO>
+__global__ __launch_bounds__(BLOCK, 2) void linear_metrics_wide_kernel(
+    const float *__restrict__ X, const float *__restrict__ Y, const float *__restrict__ packed,
+    long long n, int F, int P, int KBn, float eps, float *__restrict__ Yhat, double *__restrict__ partial,
+    int *__restrict__ far_flag)
+{
+    if (REDO && *far_flag == 0) return;
+    constexpr int STAGE = NT * 16 * 16;                 // floats of one 16-index stage of beta^T
+    constexpr int FILL = STAGE / 4;                     // 16-byte pieces of a stage
+    constexpr int FPT = (FILL + BLOCK - 1) / BLOCK;
+    __shared__ __align__(16) float bs[2][STAGE];
+    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
+    const f32x4 *__restrict__ pk4 = reinterpret_cast<const f32x4 *>(packed);
+    const float *__restrict__ bias = packed + (size_t)KBn * STAGE;
+    double sse = 0.0, sae = 0.0, sle = 0.0;
+    float smax = 0.f;
+    const long long nblocks = (n + LW_ROWS - 1) / LW_ROWS;
+    for (long long blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+        const long long m0 = blk * LW_ROWS + wv * (LW_MT * 16);
+        const float *xrow[LW_MT];
+#pragma unroll
+        for (int mt = 0; mt < LW_MT; ++mt) {
+            const long long m = m0 + 16 * mt + i;
+            xrow[mt] = X + (m < n ? m : n - 1) * F;
+        }
+        f32x4 acc[NT][LW_MT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < LW_MT; ++mt) acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 fill[FPT], xb[LW_MT];
+#pragma unroll
+        for (int u = 0; u < FPT; ++u) {
+            const int e = threadIdx.x + u * BLOCK;
+            fill[u] = pk4[e < FILL ? e : FILL - 1];
+        }
+#pragma unroll
+        for (int mt = 0; mt < LW_MT; ++mt) {
+            const int c = 4 * g;
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(xrow[mt] + (c < F ? c : 0));
+            xb[mt] = c < F ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < FPT; ++u) {
+            const int e = threadIdx.x + u * BLOCK;
+            if (e < FILL) *reinterpret_cast<f32x4 *>(&bs[0][e * 4]) = fill[u];
+        }
+        __syncthreads();
+        for (int kb = 0; kb < KBn; ++kb) {
+            // the next stage's operands (the last stage again behind the end: in bounds, unused)
+            const int kn = kb + 1 < KBn ? kb + 1 : kb;
+            f32x4 xn[LW_MT];
+#pragma unroll
+            for (int u = 0; u < FPT; ++u) {
+                const int e = threadIdx.x + u * BLOCK;
+                fill[u] = pk4[(size_t)kn * FILL + (e < FILL ? e : FILL - 1)];
+            }
+#pragma unroll
+            for (int mt = 0; mt < LW_MT; ++mt) {
+                const int c = 16 * kn + 4 * g;
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(xrow[mt] + (c < F ? c : 0));
+                xn[mt] = c < F ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            const float *st = &bs[kb & 1][i * 16 + 4 * g];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const f32x4 a = *reinterpret_cast<const f32x4 *>(st + nt * 256);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int mt = 0; mt < LW_MT; ++mt)
+                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], xb[mt][r], acc[nt][mt], 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < FPT; ++u) {
+                const int e = threadIdx.x + u * BLOCK;
+                if (e < FILL) *reinterpret_cast<f32x4 *>(&bs[(kb + 1) & 1][e * 4]) = fill[u];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int mt = 0; mt < LW_MT; ++mt) xb[mt] = xn[mt];
+        }
+        // lane (i, g) holds outputs 16 nt + 4 g .. + 3 of row m0 + 16 mt + i.  The accumulators are
+        // scored one at a time (four outputs) with the targets of the next LW_PD in flight: left
+        // alone, hipcc hoists all 2 NT loads of Y above the first use (228 VGPRs spilled at NT = 14).
+        // No branch in here (see REDO above).
+        constexpr int NACC = LW_MT * NT;
+        constexpr int LW_PD = 4;
+        // bias values and column offsets are the same in every pass: behind an opaque offset, or
+        // hipcc computes all of them ahead of the pass loop and parks them in scratch (48 stores)
+        int zero = 0;
+        asm volatile("" : "+s"(zero));
+        const float *__restrict__ bias_ = bias + zero;
+        const float *__restrict__ Y_ = Y + zero;
+        f32x4 yq[LW_PD];
+        auto y_load = [&](int q) {
+            const int mt = q / NT, nt = q % NT;
+            const long long m = m0 + 16 * mt + i;
+            const int c = 16 * nt + 4 * g;
+            return *reinterpret_cast<const f32x4 *>(Y_ + (m < n ? m : n - 1) * P + (c < P ? c : P - 4));
+        };
+        if (RESID) {
+#pragma unroll
+            for (int q = 0; q < LW_PD && q < NACC; ++q) yq[q] = y_load(q);
+        }
+#pragma unroll
+        for (int q = 0; q < NACC; ++q) {
+            const int mt = q / NT, nt = q % NT;
+            const long long m = m0 + 16 * mt + i;
+            const int c = 16 * nt + 4 * g;
+            const bool ok = m < n && c < P;
+            const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bias_ + c);
+            const f32x4 o = acc[nt][mt] + b4;
+            if (WRITE && ok) *reinterpret_cast<f32x4 *>(Yhat + m * P + c) = o;
+            if (RESID) {
+                const f32x4 y4 = yq[q % LW_PD];
+                f32x4 yv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) yv[r] = ok ? y4[r] : o[r];      // a zero residual where there is no output
+                if (q + LW_PD < NACC) yq[q % LW_PD] = y_load(q + LW_PD);
+                float sq = 0.f;
+                if (!REDO) {
+                    lm_residuals_near4<MSLE>(o, yv, eps, sse, sae, sq, smax);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = lm_log_ratio_select(__builtin_amdgcn_fmed3f(o[r], eps, LM_CLAMP_HI),
+                                                            __builtin_amdgcn_fmed3f(yv[r], eps, LM_CLAMP_HI));
+                        sq = fmaf(e, e, sq);
+                    }
+                }
+                if (MSLE) sle += (double)sq;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    if (RESID) lm_block_out(sse, sae, sle, partial, REDO);
+    if (RESID && MSLE && !REDO && !(smax <= 0.2f)) *far_flag = 1;
+}
+
+int lw_tiles(int P) { return P <= 64 ? 4 : P <= 128 ? 8 : 14; }
+
 __global__ __launch_bounds__(BLOCK) void residual_sums_kernel(const float *__restrict__ pred,
                                                              const float *__restrict__ Y,
                                                              long long count, int msle, float eps,
@@ -794,5 +1027,75 @@ extern "C" int wm_residual_sums_f32(const float *pred, const float *Y, int64_t c
     hipLaunchKernelGGL(metrics_finish_kernel, dim3(3), dim3(BLOCK), 0, st, (const double *)workspace,
                        grid, (double)count, sums);
     WM_LAUNCH_CHECK("metrics_finish_kernel");
+    return WM_OK;
+}
+
+extern "C" int wm_linear_metrics_wide_supported(int F, int P)
+{
+    return F >= 4 && F % 4 == 0 && P >= 4 && P % 4 == 0 && P <= 224 && F <= 8192;
+}
+
+extern "C" size_t wm_linear_metrics_wide_workspace_bytes(int F, int P)
+{
+    if (!wm_linear_metrics_wide_supported(F, P)) return 0;
+    const size_t NT = lw_tiles(P), KBn = (F + 15) / 16;
+    return wm_align_up((size_t)wm_num_cus() * 8 * 3 * sizeof(double), 256) +
+           wm_align_up((KBn * NT * 256 + NT * 16) * sizeof(float), 256) + 256;
+}
+
+extern "C" int wm_linear_metrics_wide_f32(const float *X, const float *Y, const double *beta, int64_t n,
+                                          int F, int P, int want_msle, float msle_eps, double *sums,
+                                          float *Yhat, void *workspace, size_t workspace_bytes,
+                                          void *stream)
+{
+    WM_REQUIRE(n >= 0 && beta && (sums || Yhat) && (n == 0 || (X && (Y || !sums))), WM_ERR_INVALID,
+               "wm_linear_metrics_wide_f32: bad arguments (sums and / or Yhat must be given; Y with sums)");
+    WM_REQUIRE(wm_linear_metrics_wide_supported(F, P), WM_ERR_UNSUPPORTED,
+               "wm_linear_metrics_wide_f32: F %% 4 == 0, P %% 4 == 0, P <= 224, F <= 8192 are implemented "
+               "(F=%d P=%d)", F, P);
+    if (n == 0) return WM_OK;
+    WM_REQUIRE((((uintptr_t)X) & 15) == 0 && (((uintptr_t)Y) & 15) == 0 && (((uintptr_t)Yhat) & 15) == 0,
+               WM_ERR_INVALID, "wm_linear_metrics_wide_f32: X, Y and Yhat must be 16-byte aligned");
+    WM_REQUIRE(wm_num_cus() > 0, WM_ERR_NO_DEVICE, "wm_linear_metrics_wide_f32: no HIP device");
+    WM_REQUIRE(workspace && (((uintptr_t)workspace) & 15) == 0 &&
+                   workspace_bytes >= wm_linear_metrics_wide_workspace_bytes(F, P),
+               WM_ERR_WORKSPACE, "wm_linear_metrics_wide_f32: 16-byte aligned workspace of %zu bytes needed, %zu given",
+               wm_linear_metrics_wide_workspace_bytes(F, P), workspace_bytes);
+    hipStream_t st = (hipStream_t)stream;
+    const int NT = lw_tiles(P), KBn = (F + 15) / 16;
+    double *partial = (double *)workspace;
+    float *packed = (float *)((char *)workspace + wm_align_up((size_t)wm_num_cus() * 8 * 3 * sizeof(double), 256));
+    const long long pk = (long long)KBn * NT * 256 + NT * 16;
+    int *far_flag = (int *)((char *)packed + wm_align_up((size_t)pk * sizeof(float), 256));
+    hipLaunchKernelGGL(lw_pack_kernel, dim3((unsigned)((pk + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, beta,
+                       F, P, NT, KBn, packed, far_flag);
+    WM_LAUNCH_CHECK("lw_pack_kernel");
+    const long long nblocks = ((long long)n + LW_ROWS - 1) / LW_ROWS;
+    const long long cap = (long long)wm_num_cus() * 2;          // two workgroups per CU (launch bounds)
+    const int grid = (int)(nblocks < cap ? nblocks : cap);
+    const bool resid = sums != nullptr, write = Yhat != nullptr, msle = resid && want_msle;
+#define LW_GO(NT_, M_, R_, W_, REDO_)                                                            \
+    hipLaunchKernelGGL((linear_metrics_wide_kernel<NT_, M_, R_, W_, REDO_>), dim3(grid), dim3(BLOCK), 0, st, X, \
+                       Y, (const float *)packed, (long long)n, F, P, KBn, msle_eps, Yhat, partial, far_flag)
+#define LW_NT(NT_)                                                                               \
+    {                                                                                            \
+        if (resid && write) { if (msle) LW_GO(NT_, true, true, true, false); else LW_GO(NT_, false, true, true, false); } \
+        else if (resid) { if (msle) LW_GO(NT_, true, true, false, false); else LW_GO(NT_, false, true, false, false); }   \
+        else LW_GO(NT_, false, false, true, false);                                              \
+        if (msle) LW_GO(NT_, true, true, false, true);                                           \
+    }
+    switch (NT) {
+    case 4: LW_NT(4) break;
+    case 8: LW_NT(8) break;
+    default: LW_NT(14) break;
+    }
+#undef LW_NT
+#undef LW_GO
+    WM_LAUNCH_CHECK("linear_metrics_wide_kernel");
+    if (resid) {
+        hipLaunchKernelGGL(metrics_finish_kernel, dim3(3), dim3(BLOCK), 0, st, (const double *)partial, grid,
+                           (double)n * (double)P, sums);
+        WM_LAUNCH_CHECK("metrics_finish_kernel");
+    }
     return WM_OK;
 }

@@ -571,25 +571,61 @@ def lstsq_fit(X, Y, fit_intercept=True, ridge=0.0):
     return normal_solve(acc, X.shape[1], Yv.shape[1], fit_intercept, ridge)
 
 
+def _wide_ok(L, F, P, *tensors):
+    """The MFMA route for wide linear maps: shape supported, every pointer 16-byte aligned, and not
+    switched off (WM_LINMETRICS_WIDE=0: probe switch)."""
+    import os
+    return (os.environ.get("WM_LINMETRICS_WIDE", "1") != "0" and bool(L.wm_linear_metrics_wide_supported(F, P))
+            and all(t.data_ptr() % 16 == 0 for t in tensors))
+
+
+def linear_wide(X, beta, Y=None, sums=None, want_msle=True, msle_eps=1e-7, predict=False):
+    """wm_linear_metrics_wide_f32: the MFMA route for wide linear maps.  Adds the residual sums
+    against ``Y`` to ``sums`` (when given) and / or returns the float32 predictions (``predict``).
+    Returns (sums, predictions or None)."""
+    L = _lib.lib()
+    n, F = X.shape
+    P = beta.shape[1]
+    out = torch.empty((n, P), device=X.device, dtype=torch.float32) if predict else None
+    if n == 0:
+        return sums, out
+    with torch.cuda.device(X.device):
+        ws = torch.empty((max(L.wm_linear_metrics_wide_workspace_bytes(F, P), 16),), device=X.device,
+                         dtype=torch.uint8)
+        _lib.check(L.wm_linear_metrics_wide_f32(
+            X.data_ptr(), None if Y is None else Y.data_ptr(), beta.data_ptr(), n, F, P,
+            int(bool(want_msle)), float(msle_eps), None if sums is None else sums.data_ptr(),
+            None if out is None else out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
+    return sums, out
+
+
 def linear_predict(X, beta):
+    """model.predict of the fitted linear map.  Narrow maps: one thread per output, float64 dot
+    products (wm_linear_predict_f32).  Wide maps (F * P >= 4096, e.g. singleRegression's 432 -> 216):
+    the MFMA kernel of wm_linear_metrics_wide_f32 writing its float32 accumulators."""
     X = _req(X, "X")
     beta = _req(beta, "beta", torch.float64)
     n, F = X.shape
     P = beta.shape[1]
     if beta.shape[0] != F + 1:
         raise ValueError(f"beta must be ({F + 1}, P), got {tuple(beta.shape)}")
+    L = _lib.lib()
+    if n > 0 and F * P >= 4096 and _wide_ok(L, F, P, X):
+        return linear_wide(X, beta, predict=True)[1]
     out = torch.empty((n, P), device=X.device, dtype=torch.float32)
     with torch.cuda.device(X.device):
-        _lib.check(_lib.lib().wm_linear_predict_f32(X.data_ptr(), beta.data_ptr(), out.data_ptr(),
-                                                    n, F, P, _stream()))
+        _lib.check(L.wm_linear_predict_f32(X.data_ptr(), beta.data_ptr(), out.data_ptr(),
+                                           n, F, P, _stream()))
     return out
 
 
 def linear_metrics(X, Y, beta, sums=None, want_msle=True, msle_eps=1e-7):
     """Add {sum d^2, sum |d|, sum (log1p diff)^2, count} of ``[X | 1] beta - Y`` to the float64[4]
     ``sums`` (created zeroed when None) in one pass over the rows -- the loss / mae / msle that
-    model.fit reports per epoch (multipleRegression.py:292-296).  Large F x P (beyond
-    wm_linear_metrics_supported) forms the predictions with a library GEMM first."""
+    model.fit reports per epoch (multipleRegression.py:292-296).  Wide maps (beyond
+    wm_linear_metrics_supported; singleRegression's 432 -> 216) take the MFMA kernel
+    wm_linear_metrics_wide_f32; shapes neither takes (P not a multiple of 4, P > 224) form the
+    predictions with a library GEMM first."""
     X = _req(X, "X")
     beta = _req(beta, "beta", torch.float64)
     Yv = _req(Y if Y.dim() == 2 else Y[:, None], "Y")
@@ -610,6 +646,10 @@ def linear_metrics(X, Y, beta, sums=None, want_msle=True, msle_eps=1e-7):
             _lib.check(L.wm_linear_metrics_f32(X.data_ptr(), Yv.data_ptr(), beta.data_ptr(), n, F, P,
                                                int(bool(want_msle)), float(msle_eps),
                                                sums.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
+        elif _wide_ok(L, F, P, X, Yv):
+            # the reference's singleRegression shape (432 -> 216): predictions on the MFMA, scored
+            # from the accumulators, never written
+            linear_wide(X, beta, Yv, sums, want_msle, msle_eps)
         else:
             b32 = beta.float()
             pred = torch.addmm(b32[F], X, b32[:F])
