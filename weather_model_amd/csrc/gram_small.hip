@@ -103,7 +103,9 @@ __global__ __launch_bounds__(BLOCK, (SmallCfg<F, P>::WPS)) void gram_small_kerne
                                                               double *__restrict__ partial)
 {
     using C = SmallCfg<F, P>;
+    using DN = wm_small::Dense<typename C::S>;
     __shared__ double red[WAVES][C::TOT * 64];
+    __shared__ __align__(16) char turn[WAVES][DN::BYTES];      // wave-private (small_stream.h)
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     const long long nwaves = (long long)gridDim.x * WAVES;
@@ -122,18 +124,20 @@ __global__ __launch_bounds__(BLOCK, (SmallCfg<F, P>::WPS)) void gram_small_kerne
         // the clamped batch of an out-of-range fetch: loads stay unconditional and in bounds
         const long long spare = wave_id % nb;
         wm_small::Buf<typename C::S> ba, bb;
-        wm_small::fetch<typename C::S>(ba, X, Y, wave_id, lane);
+        wm_small::fetch_dense<typename C::S>(ba, X, Y, wave_id, lane);
         // Two batches per trip, both consumed unconditionally (with the second consume under an
         // `if`, hipcc sinks that batch's loads into the branch and waits for them on the spot);
         // an odd last batch is consumed behind the loop.
         long long b = wave_id;
         for (; b + nwaves < nb; b += 2 * nwaves) {
-            wm_small::fetch<typename C::S>(bb, X, Y, b + nwaves, lane);
+            wm_small::fetch_dense<typename C::S>(bb, X, Y, b + nwaves, lane);
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (DN::ANY) wm_small::untangle<typename C::S>(ba, turn[wv], lane);
             small_consume<F, P>(ba, acc);
             __builtin_amdgcn_sched_barrier(0);
-            wm_small::fetch<typename C::S>(ba, X, Y, b + 2 * nwaves < nb ? b + 2 * nwaves : spare, lane);
+            wm_small::fetch_dense<typename C::S>(ba, X, Y, b + 2 * nwaves < nb ? b + 2 * nwaves : spare, lane);
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (DN::ANY) wm_small::untangle<typename C::S>(bb, turn[wv], lane);
             small_consume<F, P>(bb, acc);
             __builtin_amdgcn_sched_barrier(0);
             since += 2 * C::R * C::U;
@@ -142,7 +146,10 @@ __global__ __launch_bounds__(BLOCK, (SmallCfg<F, P>::WPS)) void gram_small_kerne
                 since = 0;
             }
         }
-        if (b < nb) small_consume<F, P>(ba, acc);
+        if (b < nb) {
+            if constexpr (DN::ANY) wm_small::untangle<typename C::S>(ba, turn[wv], lane);
+            small_consume<F, P>(ba, acc);
+        }
     }
     small_flush<F, P>(acc, tot, lane);
     // the rows behind the last full batch (fewer than ROWS_BATCH): one row per lane

@@ -316,6 +316,9 @@ __global__ __launch_bounds__(BLOCK, 2) void linear_metrics_small_kernel(
     float eps, double *__restrict__ partial)
 {
     using S = typename LmSmallCfg<F, P>::S;
+    using DN = wm_small::Dense<S>;
+    __shared__ __align__(16) char turn[BLOCK / 64][DN::BYTES];     // wave-private (small_stream.h)
+    char *tw = turn[threadIdx.x >> 6];
     const int lane = threadIdx.x & 63;
     const long long nwaves = (long long)gridDim.x * (BLOCK / 64);
     const long long wave_id = (long long)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
@@ -325,19 +328,24 @@ __global__ __launch_bounds__(BLOCK, 2) void linear_metrics_small_kernel(
     if (wave_id < nb) {
         const long long spare = wave_id % nb;          // the clamped batch of an out-of-range fetch
         wm_small::Buf<S> ba, bb;
-        wm_small::fetch<S>(ba, X, Y, wave_id, lane);
+        wm_small::fetch_dense<S>(ba, X, Y, wave_id, lane);
         long long b = wave_id;
         for (; b + nwaves < nb; b += 2 * nwaves) {
-            wm_small::fetch<S>(bb, X, Y, b + nwaves, lane);
+            wm_small::fetch_dense<S>(bb, X, Y, b + nwaves, lane);
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (DN::ANY) wm_small::untangle<S>(ba, tw, lane);
             lm_small_consume<F, P, MSLE>(ba, bt, eps, sse, sae, sle);
             __builtin_amdgcn_sched_barrier(0);
-            wm_small::fetch<S>(ba, X, Y, b + 2 * nwaves < nb ? b + 2 * nwaves : spare, lane);
+            wm_small::fetch_dense<S>(ba, X, Y, b + 2 * nwaves < nb ? b + 2 * nwaves : spare, lane);
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (DN::ANY) wm_small::untangle<S>(bb, tw, lane);
             lm_small_consume<F, P, MSLE>(bb, bt, eps, sse, sae, sle);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (b < nb) lm_small_consume<F, P, MSLE>(ba, bt, eps, sse, sae, sle);
+        if (b < nb) {
+            if constexpr (DN::ANY) wm_small::untangle<S>(ba, tw, lane);
+            lm_small_consume<F, P, MSLE>(ba, bt, eps, sse, sae, sle);
+        }
     }
     // the rows behind the last full batch (fewer than ROWS_BATCH): one row per lane
     for (long long r0 = nb * S::ROWS_BATCH + wave_id * 64; r0 < n; r0 += nwaves * 64) {
