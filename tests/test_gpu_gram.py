@@ -393,8 +393,9 @@ def test_linear_metrics_match_float64_restatement(shape):
     assert torch.equal(b, sums)
 
 
-@pytest.mark.parametrize("F,P", [(1, 1), (2, 1), (4, 2), (6, 3), (8, 4), (10, 5), (5, 3), (8, 1),
-                                 (16, 8), (12, 6), (32, 16), (16, 4), (8, 8)], ids=lambda v: str(v))
+@pytest.mark.parametrize("F,P", [(1, 1), (2, 1), (4, 2), (6, 3), (8, 4), (10, 5), (5, 3), (8, 1), (3, 1), (7, 1),
+                                 (16, 8), (12, 6), (32, 16), (16, 4), (8, 8),
+                                 (14, 7), (18, 9), (22, 11), (20, 10)], ids=lambda v: str(v))
 def test_linear_metrics_stream_kernels_tails_and_far_branch(F, P):
     """linmetrics.hip's narrow-row kernel (F + P <= 15, gram_small's memory side) and the prefetching
     tile kernel: row counts around a lane's batch (64 R U rows), a wave's tile (64 rows) and more than

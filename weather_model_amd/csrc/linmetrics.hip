@@ -234,6 +234,12 @@ __global__ __launch_bounds__(BLOCK) void linear_metrics_kernel(const float *__re
 // loads issued before the current batch's arithmetic.  beta sits in SGPRs (scalar loads at
 // uniform addresses); the float64 dot products run in the direct kernel's order (intercept first,
 // then features in order), so the predictions are the same bits.
+// Metrics only: wider rows of the family F = 2p, P = p that no other kernel here reads well (F not a
+// multiple of 4, or rows of beta that fragment the SGPR file in the tile kernel) -- without the Gram
+// kernel's F + P <= 15 limit, because this kernel keeps no accumulator per product.  F=14,P=7: 4.3
+// (lane-per-row kernel) -> 1.6 ms per 1e8 rows.
+#define WM_LM_EXTRA_SHAPES(X_) X_(14, 7) X_(18, 9) X_(22, 11) X_(20, 10)
+
 template <int F, int P>
 struct LmSmallCfg {
     static constexpr int M = F + P;
@@ -271,8 +277,23 @@ __device__ __forceinline__ void lm_small_row(const float (&x)[F], const float (&
     lm_residuals<P, MSLE>(pred, y, eps, sse, sae, sle);
 }
 
-// A batch: the predictions of all its rows first, then the residual sums of groups of up to 8
-// outputs -- one (rare) far branch per group instead of one per row, so that the rows' dependent
+// residual sums of outputs [O0, TOT) in groups of up to 8 (one rare far branch per group)
+template <int O0, int TOT, bool MSLE>
+__device__ __forceinline__ void lm_resid_groups(const float (&pred)[TOT], const float (&y)[TOT], float eps,
+                                                double &sse, double &sae, double &sle)
+{
+    if constexpr (O0 < TOT) {
+        constexpr int N = TOT - O0 < 8 ? TOT - O0 : 8;
+        lm_residuals<N, MSLE>(reinterpret_cast<const float(&)[N]>(pred[O0]),
+                              reinterpret_cast<const float(&)[N]>(y[O0]), eps, sse, sae, sle);
+        lm_resid_groups<O0 + N, TOT, MSLE>(pred, y, eps, sse, sae, sle);
+    }
+}
+
+// A batch: the predictions of ALL its rows first -- so that the scalar loads of beta are shared by the
+// rows and dead before the first branch (row by row, beta stayed live across every row's far branch:
+// 550-1554 spilled SGPRs at F=14,P=7 .. F=22,P=11) -- then the residual sums in groups of up to 8
+// outputs, one (rare) far branch per group instead of one per output, so that the outputs' dependent
 // chains (reciprocal, series, float64 square) overlap.
 template <int F, int P, bool MSLE>
 __device__ __forceinline__ void lm_small_consume(const wm_small::Buf<typename LmSmallCfg<F, P>::S> &b,
@@ -289,25 +310,53 @@ __device__ __forceinline__ void lm_small_consume(const wm_small::Buf<typename Lm
         bt += zero;
     }
     constexpr int ROWS = S::U * S::R;                       // rows of the lane in a batch
-    constexpr int G0 = 8 / P < 1 ? 1 : 8 / P;               // rows per residual group
-    constexpr int G = G0 > ROWS ? ROWS : G0;
+    float pred[ROWS * P], y[ROWS * P];
+    if constexpr ((F + 1) * P > 40) {
+        // beta streams through the SGPR file one row (P doubles) ahead of its use, features outermost
+        // and the batch's rows inside: left to itself hipcc issues all (F + 1) P scalar loads at the
+        // top of the block and parks them in VGPR lanes (550-1554 spilled SGPRs at F=14,P=7 ..
+        // F=22,P=11); the fences keep one row in flight while the previous one is used
+        double sacc[ROWS * P], bc[P];
 #pragma unroll
-    for (int g0 = 0; g0 < ROWS; g0 += G) {
-        constexpr int GP = G * P;
-        float pred[GP], y[GP];
+        for (int p = 0; p < P; ++p) bc[p] = bt[F * P + p];
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const int q = g0 + g < ROWS ? g0 + g : ROWS - 1;     // ROWS % G != 0: the last row again ...
-            const int u = q / S::R, r = q % S::R;
+        for (int q = 0; q < ROWS; ++q)
+#pragma unroll
+            for (int p = 0; p < P; ++p) sacc[q * P + p] = bc[p];
+#pragma unroll
+        for (int p = 0; p < P; ++p) bc[p] = bt[p];
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            double bn[P];
+#pragma unroll
+            for (int p = 0; p < P; ++p) bn[p] = bt[(f + 1 < F ? f + 1 : f) * P + p];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < ROWS; ++q) {
+                const double xd = (double)b.xe(q / S::R, q % S::R, f);
+#pragma unroll
+                for (int p = 0; p < P; ++p) sacc[q * P + p] = fma(xd, bc[p], sacc[q * P + p]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int p = 0; p < P; ++p) bc[p] = bn[p];
+        }
+#pragma unroll
+        for (int e = 0; e < ROWS * P; ++e) pred[e] = (float)sacc[e];
+    } else {
+#pragma unroll
+        for (int q = 0; q < ROWS; ++q) {
             float x[F];
 #pragma unroll
-            for (int m = 0; m < F; ++m) x[m] = b.xe(u, r, m);
-            lm_small_predict<F, P>(x, bt, pred + g * P);
-#pragma unroll
-            for (int m = 0; m < P; ++m) y[g * P + m] = g0 + g < ROWS ? b.ye(u, r, m) : pred[g * P + m];   // ... with a zero residual
+            for (int m = 0; m < F; ++m) x[m] = b.xe(q / S::R, q % S::R, m);
+            lm_small_predict<F, P>(x, bt, pred + q * P);
         }
-        lm_residuals<GP, MSLE>(pred, y, eps, sse, sae, sle);
     }
+#pragma unroll
+    for (int q = 0; q < ROWS; ++q)
+#pragma unroll
+        for (int m = 0; m < P; ++m) y[q * P + m] = b.ye(q / S::R, q % S::R, m);
+    lm_resid_groups<0, ROWS * P, MSLE>(pred, y, eps, sse, sae, sle);
 }
 
 template <int F, int P, bool MSLE>
@@ -921,6 +970,7 @@ extern "C" int wm_linear_metrics_f32(const float *X, const float *Y, const doubl
         small = true;                                                                          \
     }
         WM_SMALL_SHAPES(X_)
+        WM_LM_EXTRA_SHAPES(X_)
 #undef X_
     }
     bool tiled = false;
