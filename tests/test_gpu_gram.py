@@ -325,16 +325,19 @@ def test_gram_syrk_balanced_schedule_large_n(F, P):
     assert relinf(ops.gram(_dev(X), _dev(Y)).cpu().numpy(), ocpu.gram(X, Y)) < 2e-6
 
 
-@pytest.mark.parametrize("F,P", [(16, 8), (12, 6), (14, 7), (24, 12), (40, 20), (33, 7), (62, 1), (15, 1)],
-                         ids=lambda v: str(v))
+@pytest.mark.parametrize("F,P", [(16, 8), (12, 6), (14, 7), (24, 12), (40, 20), (33, 7), (62, 1), (15, 1),
+                                 (18, 9), (20, 10), (22, 11)], ids=lambda v: str(v))
 def test_gram_mid_kernel_alignments_and_tails(F, P):
     """gram_mid.hip (15 < F + P, F + P + 1 <= 64): vector-load and dword-load variants, both column
     widths (D <= 32, D <= 64), pointers moved off their 16- / 8-byte alignment, row counts around the
     k-step (4 rows), the in-flight batch and the per-wave ranges; exact on integers, and against the
-    float64 oracle on random rows."""
+    float64 oracle on random rows.  The family F = 2p, P = p for p = 6, 7, 9, 10, 11, 12 (and F=16,P=8
+    off its alignment) now takes gram_quadu_kernel (gram_quad.hip: padded pieces, dword-aligned vector
+    loads that run into the next row, last row read element by element) -- same checks; the row counts
+    below put the last row in a full tile, in a partial one and alone."""
     from weather_model_amd import ops, synth
     from oracle import cpu as ocpu
-    for n in (1, 3, 4, 5, 63, 64, 65, 8191, 8192 * 4 + 3, 300_007):
+    for n in (1, 3, 4, 5, 15, 16, 17, 63, 64, 65, 8191, 8192 * 4 + 3, 2048 * 128, 300_007):
         X, Y = _int_problem(n, F, P)
         ref = ocpu.gram(X, Y)
         a = ops.gram(_dev(X), _dev(Y)).cpu().numpy()

@@ -481,6 +481,8 @@ extern "C" size_t wm_gram_workspace_bytes(int64_t n, int F, int P)
     if (bm > b) b = bm;
     const size_t bq = wm_gram_quad_workspace_bytes(F, P);
     if (bq > b) b = bq;
+    const size_t bu = wm_gram_quadu_workspace_bytes(F, P);
+    if (bu > b) b = bu;
     return wm_align_up(b, 256);
 }
 
@@ -521,6 +523,8 @@ extern "C" int wm_gram_f32(const float *X, const float *Y, int64_t n, int F, int
         return wm_gram_small_launch(X, Y, (long long)n, F, P, acc, partial, st);
     if (wm_gram_quad_supported(X, Y, F, P))
         return wm_gram_quad_launch(X, Y, (long long)n, F, P, acc, partial, st);
+    if (wm_gram_quadu_supported(F, P))              // padded / unaligned rows of the same family
+        return wm_gram_quadu_launch(X, Y, (long long)n, F, P, acc, partial, st);
     if (wm_gram_mid_supported(F, P) && mid_preferred(F, P))
         return wm_gram_mid_launch(X, Y, (long long)n, F, P, acc, partial, st);
     return wm_gram_syrk_launch(X, Y, (long long)n, F, P, acc, workspace, st);

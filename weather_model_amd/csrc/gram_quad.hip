@@ -38,6 +38,19 @@ template <int N> __device__ __forceinline__ float q_get(const typename QVec<N>::
     else return v[r];
 }
 
+template <int R>
+__device__ __forceinline__ void q_step_z(f32x4 (&g)[R * (R + 1) / 2], float (&sz)[R], const float (&z)[R])
+{
+#pragma unroll
+    for (int r1 = 0; r1 < R; ++r1)
+#pragma unroll
+        for (int r2 = r1; r2 < R; ++r2)
+            g[q_pair(R, r1, r2)] =
+                __builtin_amdgcn_mfma_f32_4x4x1f32(z[r1], z[r2], g[q_pair(R, r1, r2)], 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < R; ++r) sz[r] += z[r];
+}
+
 template <int RX, int RY>
 __device__ __forceinline__ void q_step(f32x4 (&g)[(RX + RY) * (RX + RY + 1) / 2], float (&sz)[RX + RY],
                                        const typename QVec<RX>::type &x,
@@ -49,14 +62,7 @@ __device__ __forceinline__ void q_step(f32x4 (&g)[(RX + RY) * (RX + RY + 1) / 2]
     for (int r = 0; r < RX; ++r) z[r] = q_get<RX>(x, r);
 #pragma unroll
     for (int r = 0; r < RY; ++r) z[RX + r] = q_get<RY>(y, r);
-#pragma unroll
-    for (int r1 = 0; r1 < R; ++r1)
-#pragma unroll
-        for (int r2 = r1; r2 < R; ++r2)
-            g[q_pair(R, r1, r2)] =
-                __builtin_amdgcn_mfma_f32_4x4x1f32(z[r1], z[r2], g[q_pair(R, r1, r2)], 0, 0, 0);
-#pragma unroll
-    for (int r = 0; r < R; ++r) sz[r] += z[r];
+    q_step_z<R>(g, sz, z);
 }
 
 // add the wave's float32 sums into its LDS float64 sums: the 16 row blocks (lanes with equal
@@ -164,16 +170,147 @@ __global__ __launch_bounds__(BLOCK, 2) void gram_quad_kernel(const float *__rest
     }
 }
 
+// ---- any F, P with R = ceil(F / 4) + ceil(P / 4) <= 9 and any (4-byte) alignment: the same scheme on
+// rows that are NOT four equal pieces (six variables: F = 12, P = 6; seven: 14, 7; nine, ten, eleven).
+// Lane 4s + a still takes RX = ceil(F / 4) consecutive floats of X row s from column RX a, and RY of
+// Y, as dword-aligned vector loads (the hardware takes dword-aligned dwordx2/x3/x4); where 4 RX > F the
+// last lanes' pieces run into the next row -- in bounds for every row but the last, which the tail
+// loop reads element by element -- and those registers are zeroed by a per-lane mask computed once.
+// A wave's loads of a tile still cover one contiguous run of X (16 F floats) with a few floats read
+// twice, so the memory side is gram_quad_kernel's.  gram_mid_kernel, which these shapes took before,
+// pads Z to 32 columns of 16x16x4 tiles: 24 MFMA cycles per row against R (R + 1) / 2 / 2 here
+// (7.5 at F=12,P=6, 18 at F=20,P=10).
+template <int N>
+__device__ __forceinline__ void qu_load(const float *__restrict__ p, float *__restrict__ dst)
+{
+    if constexpr (N >= 4) {
+        const f4u v = __builtin_nontemporal_load(reinterpret_cast<const f4u *>(p));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dst[k] = v[k];
+        qu_load<N - 4>(p + 4, dst + 4);
+    } else if constexpr (N == 3) {
+        const f2u v = __builtin_nontemporal_load(reinterpret_cast<const f2u *>(p));
+        dst[0] = v[0];
+        dst[1] = v[1];
+        dst[2] = __builtin_nontemporal_load(p + 2);
+    } else if constexpr (N == 2) {
+        const f2u v = __builtin_nontemporal_load(reinterpret_cast<const f2u *>(p));
+        dst[0] = v[0];
+        dst[1] = v[1];
+    } else if constexpr (N == 1) {
+        dst[0] = __builtin_nontemporal_load(p);
+    }
+}
+
+template <int F, int P>
+struct QuCfg {
+    static constexpr int RX = (F + 3) / 4, RY = (P + 3) / 4, R = RX + RY;
+    static constexpr int NP = R * (R + 1) / 2, NVAL = NP * 4 + R, PART = NVAL * 4;
+    static constexpr bool MASKX = 4 * RX != F, MASKY = 4 * RY != P;
+    // tiles per batch: two batches of U (R floats each) beside 4 NP accumulator registers
+    static constexpr int U = R <= 6 ? 8 : (R <= 8 ? 4 : 2);
+    static_assert(R <= 9, "gram_quadu: ceil(F/4) + ceil(P/4) <= 9");
+};
+
+template <int F, int P>
+__global__ __launch_bounds__(BLOCK, 2) void gram_quadu_kernel(const float *__restrict__ X,
+                                                              const float *__restrict__ Y, long long n,
+                                                              double *__restrict__ partial)
+{
+    using C = QuCfg<F, P>;
+    constexpr int R = C::R, RX = C::RX, RY = C::RY, NP = C::NP, U = C::U;
+    __shared__ double red[WAVES][C::NVAL][4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int a = lane & 3, srow = lane >> 2;
+    const long long nwaves = (long long)gridDim.x * WAVES;
+    const long long wave_id = (long long)blockIdx.x * WAVES + wv;
+    const long long tiles = (n + 15) >> 4;
+    // tiles whose vector loads stay inside the arrays: all full tiles but the one holding the last row
+    const long long safe_tiles = (C::MASKX || C::MASKY) ? (n - 1 > 0 ? (n - 1) >> 4 : 0) : (n >> 4);
+    for (int i = lane; i < C::PART; i += 64) (&red[wv][0][0])[i] = 0.0;
+    f32x4 g[NP];
+    float sz[R];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) g[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < R; ++r) sz[r] = 0.f;
+    bool live[R];                                  // this lane's register holds a column of Z
+#pragma unroll
+    for (int r = 0; r < RX; ++r) live[r] = a * RX + r < F;
+#pragma unroll
+    for (int r = 0; r < RY; ++r) live[RX + r] = a * RY + r < P;
+    const float *__restrict__ xl = X + (long long)srow * F + a * RX;
+    const float *__restrict__ yl = Y + (long long)srow * P + a * RY;
+    int since_flush = 0;
+    const long long nb = safe_tiles / U;
+    auto fetch = [&](float(&z)[U][R], long long bq) __attribute__((always_inline)) {
+        const long long t_ = (bq < nb ? bq : wave_id % (nb > 0 ? nb : 1)) * U;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            qu_load<RX>(xl + (t_ + u) * 16 * F, &z[u][0]);
+            qu_load<RY>(yl + (t_ + u) * 16 * P, &z[u][RX]);
+        }
+    };
+    auto consume = [&](float(&z)[U][R]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if constexpr (C::MASKX || C::MASKY) {
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    if ((r < RX && C::MASKX) || (r >= RX && C::MASKY)) z[u][r] = live[r] ? z[u][r] : 0.f;
+            }
+            q_step_z<R>(g, sz, z[u]);
+        }
+        since_flush += U;
+        if (since_flush >= Q_FLUSH_TILES) {
+            q_flush<NP, R>(g, sz, red[wv], lane);
+            since_flush = 0;
+        }
+    };
+    if (wave_id < nb) {
+        float za[U][R], zb[U][R];
+        fetch(za, wave_id);
+        for (long long b = wave_id; b < nb; b += 2 * nwaves) {
+            fetch(zb, b + nwaves);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(za);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(za, b + 2 * nwaves);
+            __builtin_amdgcn_sched_barrier(0);
+            if (b + nwaves < nb) consume(zb);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // the tiles behind the last full batch (and the one with the last row): element by element
+    for (long long t = nb * U + wave_id; t < tiles; t += nwaves) {
+        const long long row = t * 16 + srow;
+        float z[R];
+#pragma unroll
+        for (int r = 0; r < RX; ++r) z[r] = (row < n && a * RX + r < F) ? X[row * F + a * RX + r] : 0.f;
+#pragma unroll
+        for (int r = 0; r < RY; ++r) z[RX + r] = (row < n && a * RY + r < P) ? Y[row * P + a * RY + r] : 0.f;
+        q_step_z<R>(g, sz, z);
+    }
+    q_flush<NP, R>(g, sz, red[wv], lane);
+    __syncthreads();
+    for (int i = threadIdx.x; i < C::PART; i += BLOCK) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) s += (&red[w][0][0])[i];
+        partial[(size_t)blockIdx.x * C::PART + i] = s;
+    }
+}
+
 // acc (D x D, D = F + 1 + P) += fixed-order sum of the per-workgroup partials; one wave per entry.
 // Column c of Z: c < F -> lane residue c / RX, register c % RX; c = F -> the ones; c > F -> residue
 // (c - F - 1) / RY, register RX + (c - F - 1) % RY.  mfma(A = reg r1, B = reg r2): accumulator
 // register a', lane residue b' holds sum_rows Z[row][col(a', r1)] * Z[row][col(b', r2)].
 __global__ __launch_bounds__(64) void gram_quad_finalize_kernel(const double *__restrict__ partial,
                                                                 int nparts, long long n, int RX, int RY,
-                                                                double *__restrict__ acc)
+                                                                int F, int P, double *__restrict__ acc)
 {
     const int R = RX + RY, NP = R * (R + 1) / 2, PART = (NP * 4 + R) * 4;
-    const int F = 4 * RX, D = F + 1 + 4 * RY;
+    const int D = F + 1 + P;                     // F <= 4 RX, P <= 4 RY (gram_quadu: padded pieces)
     const int e = blockIdx.x;
     const int ci = e / D, cj = e % D;
     int ai = 0, ri = -1, aj = 0, rj = -1;            // r = -1: the ones column
@@ -252,7 +389,48 @@ int wm_gram_quad_launch(const float *X, const float *Y, long long n, int F, int 
     WM_LAUNCH_CHECK("gram_quad_kernel");
     const int D = F + 1 + P;
     hipLaunchKernelGGL(gram_quad_finalize_kernel, dim3(D * D), dim3(64), 0, st,
-                       (const double *)partial, grid, n, rx, ry, acc);
+                       (const double *)partial, grid, n, rx, ry, F, P, acc);
+    WM_LAUNCH_CHECK("gram_quad_finalize_kernel");
+    return WM_OK;
+}
+
+// the padded / unaligned variant: shapes of the family F = 2p, P = p (and their (F, 1) cousins are
+// gram_small's or gram_mid's) that the aligned kernel above does not take
+#define WM_QUADU_SHAPES(X_) X_(12, 6) X_(14, 7) X_(18, 9) X_(20, 10) X_(22, 11) X_(24, 12) X_(16, 8)
+
+bool wm_gram_quadu_supported(int F, int P)
+{
+    static const bool off = [] { const char *e = getenv("WM_GRAM_QUADU"); return e && e[0] == '0'; }();
+    if (off) return false;                     // probe switch: A/B against gram_mid
+#define X_(F_, P_) if (F == F_ && P == P_) return true;
+    WM_QUADU_SHAPES(X_)
+#undef X_
+    return false;
+}
+
+size_t wm_gram_quadu_workspace_bytes(int F, int P)
+{
+    if (!wm_gram_quadu_supported(F, P) || wm_num_cus() <= 0) return 0;
+    return (size_t)quad_grid() * q_part((F + 3) / 4, (P + 3) / 4) * sizeof(double);
+}
+
+int wm_gram_quadu_launch(const float *X, const float *Y, long long n, int F, int P, double *acc,
+                         double *partial, hipStream_t st)
+{
+    const int grid = quad_grid();
+    bool launched = false;
+#define X_(F_, P_)                                                                               \
+    if (F == F_ && P == P_) {                                                                    \
+        hipLaunchKernelGGL((gram_quadu_kernel<F_, P_>), dim3(grid), dim3(BLOCK), 0, st, X, Y, n, partial); \
+        launched = true;                                                                         \
+    }
+    WM_QUADU_SHAPES(X_)
+#undef X_
+    WM_REQUIRE(launched, WM_ERR_UNSUPPORTED, "gram_quadu: F=%d P=%d not instantiated", F, P);
+    WM_LAUNCH_CHECK("gram_quadu_kernel");
+    const int D = F + 1 + P;
+    hipLaunchKernelGGL(gram_quad_finalize_kernel, dim3(D * D), dim3(64), 0, st,
+                       (const double *)partial, grid, n, (F + 3) / 4, (P + 3) / 4, F, P, acc);
     WM_LAUNCH_CHECK("gram_quad_finalize_kernel");
     return WM_OK;
 }
