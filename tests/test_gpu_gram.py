@@ -326,7 +326,7 @@ def test_gram_syrk_balanced_schedule_large_n(F, P):
 
 
 @pytest.mark.parametrize("F,P", [(16, 8), (12, 6), (14, 7), (24, 12), (40, 20), (33, 7), (62, 1), (15, 1),
-                                 (18, 9), (20, 10), (22, 11)], ids=lambda v: str(v))
+                                 (18, 9), (20, 10), (22, 11), (32, 16)], ids=lambda v: str(v))
 def test_gram_mid_kernel_alignments_and_tails(F, P):
     """gram_mid.hip (15 < F + P, F + P + 1 <= 64): vector-load and dword-load variants, both column
     widths (D <= 32, D <= 64), pointers moved off their 16- / 8-byte alignment, row counts around the

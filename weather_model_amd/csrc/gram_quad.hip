@@ -209,11 +209,14 @@ struct QuCfg {
     static constexpr bool MASKX = 4 * RX != F, MASKY = 4 * RY != P;
     // tiles per batch: two batches of U (R floats each) beside 4 NP accumulator registers
     static constexpr int U = R <= 6 ? 8 : (R <= 8 ? 4 : 2);
+    // beyond R = 9 the 4 NP accumulator registers alone pass 256; F=32,P=16 (R = 12) with one wave per
+    // SIMD and 512 registers was tried: 360 VGPRs, no spill reported, 71 ms against gram_mid's 1.9
+    static constexpr int WPS = 2;
     static_assert(R <= 9, "gram_quadu: ceil(F/4) + ceil(P/4) <= 9");
 };
 
 template <int F, int P>
-__global__ __launch_bounds__(BLOCK, 2) void gram_quadu_kernel(const float *__restrict__ X,
+__global__ __launch_bounds__(BLOCK, (QuCfg<F, P>::WPS)) void gram_quadu_kernel(const float *__restrict__ X,
                                                               const float *__restrict__ Y, long long n,
                                                               double *__restrict__ partial)
 {
@@ -417,10 +420,11 @@ size_t wm_gram_quadu_workspace_bytes(int F, int P)
 int wm_gram_quadu_launch(const float *X, const float *Y, long long n, int F, int P, double *acc,
                          double *partial, hipStream_t st)
 {
-    const int grid = quad_grid();
+    int grid = quad_grid();
     bool launched = false;
 #define X_(F_, P_)                                                                               \
     if (F == F_ && P == P_) {                                                                    \
+        grid = wm_num_cus() * QuCfg<F_, P_>::WPS;                                                \
         hipLaunchKernelGGL((gram_quadu_kernel<F_, P_>), dim3(grid), dim3(BLOCK), 0, st, X, Y, n, partial); \
         launched = true;                                                                         \
     }
