@@ -352,7 +352,68 @@ def gram_kernel_name(F, P):
         return "gram_small_kernel"
     if (F, P) in ((16, 8), (16, 4), (8, 8)):
         return "gram_quad_kernel"
+    if (F, P) in ((12, 6), (14, 7), (18, 9), (20, 10), (22, 11), (24, 12)):
+        return "gram_quadu_kernel"
     return "gram_mid_kernel" if F + P + 1 <= 64 else "gram_syrk_kernel"
+
+
+def run_gram_family(rank, world, ps=(3, 5, 6, 7, 10, 12), bytes_target=4.8e9):
+    """The rest of multipleRegression's family F = 2p, P = p (p variables at CUBE_SIZE 1,
+    multipleRegression.py:273-286): the Gram pass and the loss / mae / msle pass of an epoch on
+    resident rows, each bracketed by HIP events -- short (about 4.8 GB of rows per shape, six timed
+    launches), so that the default line carries a measured figure for every kernel family the fit can
+    take (narrow-row stream with dense loads, padded quad MFMA, narrow metrics, tile metrics)."""
+    from weather_model_amd import ops, synth, _lib
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    out = {}
+    for p_ in ps:
+        F, P = 2 * p_, p_
+        n = int(bytes_target / (4 * (F + P))) // 4096 * 4096
+        X = torch.empty((n, F), device="cuda", dtype=torch.float32)
+        Y = torch.empty((n, P), device="cuda", dtype=torch.float32)
+        bt = torch.from_numpy(synth.normal(1001, (F, P))).cuda()
+        _lib.check(L.wm_synth_uniform_f32(X.data_ptr(), n * F, 1, rank * n * F, 0.0, 1.0, st))
+        _lib.check(L.wm_synth_uniform_f32(Y.data_ptr(), n * P, 2001, rank * n * P,
+                                          -0.01 * 3 ** 0.5, 0.01 * 3 ** 0.5, st))
+        for s0 in range(0, n, 250_000):
+            Y[s0:s0 + 250_000].add_(X[s0:s0 + 250_000] @ bt + 0.5)
+        plan = ops.GramPlan(n, F, P, "cuda")
+        sums = torch.zeros((4,), device="cuda", dtype=torch.float64)
+        plan.acc.zero_()
+        plan.accumulate(X, Y)
+        plan.solve()
+        gev, mev = [], []
+        for i in range(8):
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            plan.acc.zero_()
+            e[0].record()
+            plan.accumulate(X, Y)
+            e[1].record()
+            sums.zero_()
+            e[2].record()
+            ops.linear_metrics(X, Y, plan.beta, sums)
+            e[3].record()
+            if i >= 2:
+                gev.append((e[0], e[1]))
+                mev.append((e[2], e[3]))
+        torch.cuda.synchronize()
+        gms = float(np.mean([a.elapsed_time(b) for a, b in gev]))
+        mms = float(np.mean([a.elapsed_time(b) for a, b in mev]))
+        gb = 4.0 * (F + P) * n / 1e6
+        out[f"F{F}_P{P}"] = {
+            "rows": n, "gram_ms": gms, "gram_GBs": gb / gms, "gram_frac": gb / gms / HBM_PEAK_GBS,
+            "gram_kernel": gram_kernel_name(F, P), "metrics_ms": mms, "metrics_GBs": gb / mms,
+            "metrics_frac": gb / mms / HBM_PEAK_GBS, "mse": float(sums[0] / sums[3]),
+            "planted_coef_max_err": float((plan.beta[:F].float() - bt).abs().max())}
+        del X, Y, plan
+        torch.cuda.empty_cache()
+    return {"unit": "GB/s of 4(F+P) algorithmic bytes per row (HBM-bound: F/2 flop/B < 19.7)",
+            "config": {"workload": "multipleRegression's family F = 2p, P = p for p = "
+                                   + ", ".join(str(v) for v in ps)
+                                   + ": Gram pass and loss/mae/msle pass on resident rows, HIP events, "
+                                     "6 timed launches each"},
+            "shapes": out}
 
 
 def run_gram(F, n_rows, steps, warmup, rank, world, cpu_base, P=1, dist="uniform"):
@@ -1302,7 +1363,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="all", choices=["all", "gram16", "conv3x3", "gram64", "model32", "fields", "conv32", "conv32x3",
-                             "conv3d_model", "plumbing", "gram_ref_multi", "gram_ref_single", "gram_mid",
+                             "conv3d_model", "plumbing", "gram_ref_multi", "gram_ref_single", "gram_mid", "gram_family",
                              "gram16_normal"])
     ap.add_argument("--rows", type=int, default=100_000_000, help="rows per GPU (gram16)")
     ap.add_argument("--rows64", type=int, default=1_250_000_000,
@@ -1396,6 +1457,18 @@ def main():
                     out[k] = r[k]
         else:
             out.setdefault("also", {})[name] = r
+    if args.workload in ("all", "gram_family"):
+        fam = run_gram_family(rank, world)
+        if args.workload == "gram_family":
+            best = max(fam["shapes"].values(), key=lambda v: v["gram_frac"])
+            out.update({"metric": "regression rows/s (multipleRegression family F = 2p, P = p)",
+                        "value": best["rows"] / best["gram_ms"] * 1e3 * world, "ms_per_step": best["gram_ms"],
+                        "config": fam["config"], "roofline": {
+                            "bound": "hbm", "achieved": best["gram_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": best["gram_frac"], "traffic": None, "kernel": best["gram_kernel"]},
+                        "shapes": fam["shapes"]})
+        else:
+            out.setdefault("also", {})["gram_family"] = fam
     if args.workload in ("all", "gram64"):
         # config 5: 1e10 rows over 8 GPUs = 1.25e9 rows per GPU; a pass takes ~0.25 s, so the default
         # run keeps the full per-GPU size but caps the step count
