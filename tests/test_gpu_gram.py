@@ -398,14 +398,16 @@ def test_linear_metrics_match_float64_restatement(shape):
 
 @pytest.mark.parametrize("F,P", [(1, 1), (2, 1), (4, 2), (6, 3), (8, 4), (10, 5), (5, 3), (8, 1), (3, 1), (7, 1),
                                  (16, 8), (12, 6), (32, 16), (16, 4), (8, 8),
-                                 (14, 7), (18, 9), (22, 11), (20, 10)], ids=lambda v: str(v))
+                                 (14, 7), (18, 9), (22, 11), (20, 10), (24, 12)], ids=lambda v: str(v))
 def test_linear_metrics_stream_kernels_tails_and_far_branch(F, P):
     """linmetrics.hip's narrow-row kernel (F + P <= 15, gram_small's memory side) and the prefetching
     tile kernel: row counts around a lane's batch (64 R U rows), a wave's tile (64 rows) and more than
     one batch per wave; targets UNRELATED to the predictions, so that many outputs take the far form
     of log1p(a) - log1p(b) (the two differ by more than a factor 1.5) beside near ones in the same
     wave, plus values below eps and beyond the 1e37 clamp; msle on and off; pointers off their
-    alignment take another kernel and must agree to rounding."""
+    alignment take another kernel and must agree to rounding.  F=18,P=9 .. F=24,P=12 take the
+    float64-MFMA kernel (flat LDS tiles, trimmed last feature block, partial last tile with a row
+    tail that is not a whole 16-byte piece)."""
     from weather_model_amd import ops
     rng = np.random.default_rng(F * 31 + P)
     beta = rng.uniform(-0.5, 0.5, (F + 1, P))

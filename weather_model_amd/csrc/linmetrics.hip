@@ -13,6 +13,8 @@
 //                                     the caller forms them with a library GEMM)
 //   partials are per workgroup, float64, combined in a fixed order by metrics_finish_kernel and ADDED
 //   to sums[4] = {sum d^2, sum |d|, sum (log1p(max(pred,eps)) - log1p(max(y,eps)))^2, count}.
+#include <type_traits>
+
 #include "common.h"
 #include "small_stream.h"
 
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(BLOCK) void linear_metrics_kernel(const float *__re
 // multiple of 4, or rows of beta that fragment the SGPR file in the tile kernel) -- without the Gram
 // kernel's F + P <= 15 limit, because this kernel keeps no accumulator per product.  F=14,P=7: 4.3
 // (lane-per-row kernel) -> 1.6 ms per 1e8 rows.
-#define WM_LM_EXTRA_SHAPES(X_) X_(14, 7) X_(18, 9) X_(22, 11) X_(20, 10)
+#define WM_LM_EXTRA_SHAPES(X_) X_(14, 7) X_(18, 9) X_(22, 11) X_(20, 10)   /* all but (14,7): behind the float64-MFMA kernel */
 
 template <int F, int P>
 struct LmSmallCfg {
@@ -680,6 +682,176 @@ __global__ __launch_bounds__(BLOCK) void linear_metrics_tile_kernel(
     lm_block_out(sse, sae, sle, partial);
 }
 
+// ---- F = 2p, P = p with 6 < p <= 16 (rows of beta that are neither short enough for the SGPR file
+// nor 8 / 16 doubles long): the float64 dot products on the float64 MFMA.  v_mfma_f64_16x16x4_f64
+// computes D[16 rows][16 outputs] += A[16 rows][4 features] B[4 features][16 outputs] in float64, so
+// the predictions keep the narrow kernels' arithmetic (float64 sums of float32 x float64 products,
+// rounded to float32 once) while beta sits in VGPRs -- lane (i, g) holds beta[f][n = i] for its own
+// four features of every 16-feature block, 2 ceil(F / 16) x 4 registers, loaded once per kernel -- and
+// no scalar register is involved: the scalar-beta kernels above lose 500-1500 SGPRs to VGPR lanes at
+// P = 7, 9, 10, 11, 12 (F=24,P=12 ran at 0.37 of HBM, F=20,P=10 at 0.48).
+//   A wave's tile of 64 rows is one contiguous run of X and one of Y: copied flat into a wave-private
+//   LDS region by 16-byte pieces (the next tile's pieces in flight while this one is computed).  Lane
+//   (i, g) reads 16 bytes -- features 16 kb + 4 g .. + 3 of row 16 m + i -- per 16-feature block and
+//   row block m, and MFMA step r uses element r of them and register r of beta (the contraction order
+//   inside a block is free as long as both operands agree); the last block takes only as many steps
+//   as its features need.  D: lane (i, g) holds output n = i of rows
+//   16 m + g + 4 r; lanes with i >= P carry zeros.  Targets come back from the LDS copy of Y.
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+// Measured (6e7 rows): F=24,P=12 0.37 -> 0.65 of HBM, 20,10 0.48 -> 0.65, 22,11 0.30 -> 0.62, 18,9 0.46 ->
+// 0.62; without the msle term 0.76-0.81.  Three waves per SIMD (138-148 VGPRs; four spill).  F=14,P=7
+// stays on the narrow-row kernel (0.65 there, 0.58 here: 9 of 16 output columns are padding), and
+// F=16,P=8 / 32,16 on the scalar-beta tile kernel (equal or faster).
+#define WM_LM_MFMA64_SHAPES(X_) X_(24, 12) X_(20, 10) X_(22, 11) X_(18, 9)
+
+template <int F, int P>
+struct LmM64 {
+    static constexpr int KB = (F + 15) / 16;                // 16-feature blocks
+    static constexpr int XP = 64 * F / 4, YP = 64 * P / 4;  // 16-byte pieces of a tile (64 F, 64 P: whole)
+    static constexpr int XL = (XP + 63) / 64, YL = (YP + 63) / 64;     // per lane
+    static constexpr int WAVE_BYTES = 64 * (F + P) * 4;
+    static constexpr bool VEC = F % 4 == 0;                 // vector LDS reads of a row's features
+    // MFMA steps of block kb: four, but the last block takes only as many as its features need --
+    // lane group g then owns `steps` consecutive features from 16 kb + g * steps (F = 20: 4 + 1 steps
+    // instead of 8, F = 24: 4 + 2)
+    static constexpr int REM = F - 16 * (KB - 1);
+    static constexpr int steps(int kb) { return kb < KB - 1 ? 4 : (REM + 3) / 4; }
+};
+
+template <int F, int P, bool MSLE>
+__global__ __launch_bounds__(BLOCK, 3) void linear_metrics_mfma64_kernel(
+    const float *__restrict__ X, const float *__restrict__ Y, const double *__restrict__ beta, long long n,
+    float eps, double *__restrict__ partial)
+{
+    using C = LmM64<F, P>;
+    extern __shared__ __align__(16) char lds[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+    float *xs = reinterpret_cast<float *>(lds + wv * C::WAVE_BYTES);
+    float *ys = xs + 64 * F;
+    // beta operands: step (kb, r) contracts features 16 kb + 4 g + r; intercept as the accumulators' start
+    double bop[C::KB][4];
+#pragma unroll
+    for (int kb = 0; kb < C::KB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int f = 16 * kb + C::steps(kb) * g + r;
+            const bool ok = r < C::steps(kb) && f < F && i < P;
+            bop[kb][r] = ok ? beta[(size_t)(f < F ? f : 0) * P + (i < P ? i : 0)] : 0.0;
+        }
+    const double b0 = i < P ? beta[(size_t)F * P + i] : 0.0;
+    double sse = 0.0, sae = 0.0, sle = 0.0;
+    const long long tiles = (n + 63) >> 6;
+    const long long stride = (long long)gridDim.x * (BLOCK / 64);
+    long long t = (long long)blockIdx.x * (BLOCK / 64) + wv;
+    f32x4 px[C::XL], py[C::YL];
+    auto tile_load = [&](long long tl) __attribute__((always_inline)) {
+        const long long row0 = tl << 6;
+        const int rows = (int)(n - row0 < 64 ? n - row0 : 64);
+        const f32x4 *xsrc = reinterpret_cast<const f32x4 *>(X + row0 * F);
+        const f32x4 *ysrc = reinterpret_cast<const f32x4 *>(Y + row0 * P);
+        // pieces that lie wholly inside the rows that exist (a partial last tile: the copy's tail is
+        // stale LDS, which only rows >= `rows` read)
+        const int xlast = rows * F / 4 - 1, ylast = rows * P / 4 - 1;
+#pragma unroll
+        for (int k = 0; k < C::XL; ++k) {
+            const int q = lane + 64 * k;
+            px[k] = __builtin_nontemporal_load(xsrc + (q <= xlast ? q : (xlast < 0 ? 0 : xlast)));
+        }
+#pragma unroll
+        for (int k = 0; k < C::YL; ++k) {
+            const int q = lane + 64 * k;
+            py[k] = __builtin_nontemporal_load(ysrc + (q <= ylast ? q : (ylast < 0 ? 0 : ylast)));
+        }
+    };
+    if (t < tiles) tile_load(t);
+    for (; t < tiles; t += stride) {
+        const long long row0 = t << 6;
+        const int rows = (int)(n - row0 < 64 ? n - row0 : 64);
+#pragma unroll
+        for (int k = 0; k < C::XL; ++k) {
+            const int q = lane + 64 * k;
+            if (C::XP % 64 == 0 || q < C::XP) *reinterpret_cast<f32x4 *>(xs + 4 * q) = px[k];
+        }
+#pragma unroll
+        for (int k = 0; k < C::YL; ++k) {
+            const int q = lane + 64 * k;
+            if (C::YP % 64 == 0 || q < C::YP) *reinterpret_cast<f32x4 *>(ys + 4 * q) = py[k];
+        }
+        __builtin_amdgcn_wave_barrier();
+        tile_load(t + stride < tiles ? t + stride : t);
+        __builtin_amdgcn_sched_barrier(0);
+        if (rows < 64) {
+            // a partial tile: the rows that do not exist are read as features too -- make them finite
+            // (the tail of rows * F floats that were not copied may hold anything, NaN included)
+            for (int e = rows * F + lane; e < 64 * F; e += 64) xs[e] = 0.0f;
+            for (int e = rows * P + lane; e < 64 * P; e += 64) ys[e] = 0.0f;
+            // and the up to three floats of the last row behind the last whole piece (rows * F not a
+            // multiple of 4): straight from global memory
+            const int xe = rows * F / 4 * 4 + lane, ye = rows * P / 4 * 4 + lane;
+            if (xe < rows * F) xs[xe] = X[row0 * F + xe];
+            if (ye < rows * P) ys[ye] = Y[row0 * P + ye];
+            __builtin_amdgcn_wave_barrier();
+        }
+        f64x4 acc[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[m] = (f64x4){b0, b0, b0, b0};
+        auto block = [&](auto kbc) __attribute__((always_inline)) {
+            constexpr int kb = decltype(kbc)::value;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                constexpr int ST = C::steps(kb);
+                const int f0 = 16 * kb + ST * g;
+                const float *xr = xs + (16 * m + i) * F + f0;
+                float xv[4] = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (C::VEC && ST == 4) {
+                    // the piece exists whole or not at all (then beta is zero, and the address is
+                    // pulled back inside the row so that no NaN of a neighbour leaks in)
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(f0 < F ? xr : xr - f0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) xv[r] = v[r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < ST; ++r) xv[r] = f0 + r < F ? xr[r] : 0.0f;
+                }
+#pragma unroll
+                for (int r = 0; r < ST; ++r)
+                    acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)xv[r], bop[kb][r], acc[m], 0, 0, 0);
+            }
+        };
+        static_assert(C::KB <= 4, "linear_metrics_mfma64_kernel: F <= 64");
+        block(std::integral_constant<int, 0>{});
+        if constexpr (C::KB > 1) block(std::integral_constant<int, 1>{});
+        if constexpr (C::KB > 2) block(std::integral_constant<int, 2>{});
+        if constexpr (C::KB > 3) block(std::integral_constant<int, 3>{});
+        // lane (i, g) holds output i of rows 16 m + g + 4 r -- and the lanes with i >= P nothing.
+        // Scored there, every lane would sit through 16 outputs (at P = 7 more than half of them
+        // padding); instead the predictions go back through the X region of the LDS tile as
+        // [row][P], like the copy of Y beside it, and lane l scores the P outputs of row l.
+        __builtin_amdgcn_wave_barrier();               // every lane's operand reads of xs are done
+        if (i < P) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xs[(16 * m + g + 4 * r) * P + i] = (float)acc[m][r];
+        }
+        __builtin_amdgcn_wave_barrier();
+        {
+            float pred[P], yv[P];
+            const bool ok = lane < rows;
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const float pp = xs[lane * P + p], yy = ys[lane * P + p];
+                pred[p] = ok ? pp : 0.0f;
+                yv[p] = ok ? yy : 0.0f;
+            }
+            lm_resid_groups<0, P, MSLE>(pred, yv, eps, sse, sae, sle);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_wave_barrier();
+    }
+    lm_block_out(sse, sae, sle, partial);
+}
+
 // ---- wide shapes (the reference's singleRegression fit is F = 432, P = 216: singleRegression.py:21,33,
 // 74-85): (F + 1) P coefficients do not fit registers or the scalar cache, and 2 F P flop per row is
 // MFMA work (186 624 flop against 2 592 bytes).  Until now the predictions were a library GEMM into a
@@ -911,6 +1083,12 @@ bool lm_untiled_forced()                   // probe switch: WM_LINMETRICS_TILE=0
     return v;
 }
 
+bool lm_mfma64_off()                       // probe switch: WM_LINMETRICS_MFMA64=0 keeps the scalar-beta routes
+{
+    static const bool v = [] { const char *e = getenv("WM_LINMETRICS_MFMA64"); return e && e[0] == '0'; }();
+    return v;
+}
+
 int lm_grid(long long units)
 {
     long long g = (units + BLOCK - 1) / BLOCK;
@@ -956,6 +1134,32 @@ extern "C" int wm_linear_metrics_f32(const float *X, const float *Y, const doubl
     const bool staged = vec && F >= 8 && staged_lds <= 64 * 1024 && !lm_direct_forced();
     double *partial = (double *)workspace;
     int grid = 0;
+    bool m64 = false;
+    if (!lm_direct_forced() && !lm_mfma64_off() && ((((uintptr_t)X) | ((uintptr_t)Y)) & 15) == 0) {
+#define X_(F_, P_)                                                                             \
+    if (F == F_ && P == P_) {                                                                  \
+        const long long want = ((n + 63) / 64 + BLOCK / 64 - 1) / (BLOCK / 64);                \
+        const long long cap = (long long)wm_num_cus() * 8;                                     \
+        grid = (int)(want < cap ? want : cap);                                                 \
+        const size_t lds = (size_t)(BLOCK / 64) * LmM64<F_, P_>::WAVE_BYTES;                   \
+        if (want_msle)                                                                         \
+            hipLaunchKernelGGL((linear_metrics_mfma64_kernel<F_, P_, true>), dim3(grid), dim3(BLOCK), \
+                               lds, st, X, Y, beta, (long long)n, msle_eps, partial);          \
+        else                                                                                   \
+            hipLaunchKernelGGL((linear_metrics_mfma64_kernel<F_, P_, false>), dim3(grid), dim3(BLOCK), \
+                               lds, st, X, Y, beta, (long long)n, msle_eps, partial);          \
+        m64 = true;                                                                            \
+    }
+        WM_LM_MFMA64_SHAPES(X_)
+#undef X_
+    }
+    if (m64) {
+        WM_LAUNCH_CHECK("linear_metrics_mfma64_kernel");
+        hipLaunchKernelGGL(metrics_finish_kernel, dim3(3), dim3(BLOCK), 0, st, (const double *)partial, grid,
+                           (double)n * (double)P, sums);
+        WM_LAUNCH_CHECK("metrics_finish_kernel");
+        return WM_OK;
+    }
     bool small = false;
     if (!lm_direct_forced()) {
 #define X_(F_, P_)                                                                             \
