@@ -1089,6 +1089,12 @@ bool lm_mfma64_off()                       // probe switch: WM_LINMETRICS_MFMA64
     return v;
 }
 
+int lm_cap_per_cu(int dflt)                // probe switch: WM_LINMETRICS_CAP=<workgroups per CU> for the tile kernels
+{
+    static const int v = [] { const char *e = getenv("WM_LINMETRICS_CAP"); return e ? atoi(e) : 0; }();
+    return v > 0 ? v : dflt;
+}
+
 int lm_grid(long long units)
 {
     long long g = (units + BLOCK - 1) / BLOCK;
@@ -1139,7 +1145,7 @@ extern "C" int wm_linear_metrics_f32(const float *X, const float *Y, const doubl
 #define X_(F_, P_)                                                                             \
     if (F == F_ && P == P_) {                                                                  \
         const long long want = ((n + 63) / 64 + BLOCK / 64 - 1) / (BLOCK / 64);                \
-        const long long cap = (long long)wm_num_cus() * 8;                                     \
+        const long long cap = (long long)wm_num_cus() * lm_cap_per_cu(8);                      \
         grid = (int)(want < cap ? want : cap);                                                 \
         const size_t lds = (size_t)(BLOCK / 64) * LmM64<F_, P_>::WAVE_BYTES;                   \
         if (want_msle)                                                                         \
@@ -1182,7 +1188,7 @@ extern "C" int wm_linear_metrics_f32(const float *X, const float *Y, const doubl
 #define X_(QX_, P_)                                                                            \
     if (F == 4 * QX_ && P == P_ && (!LmTile<QX_, P_>::VECY || (((uintptr_t)Y) & 15) == 0)) {   \
         const long long want = ((n + 63) / 64 + BLOCK / 64 - 1) / (BLOCK / 64);                \
-        const long long cap = (long long)wm_num_cus() * 8;                                     \
+        const long long cap = (long long)wm_num_cus() * lm_cap_per_cu(8);                      \
         grid = (int)(want < cap ? want : cap);                                                 \
         const size_t lds = (size_t)(BLOCK / 64) * LmTile<QX_, P_>::WAVE_BYTES;                 \
         if (want_msle)                                                                         \
