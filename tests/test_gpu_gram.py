@@ -536,6 +536,47 @@ def test_linear_metrics_full_size_properties():
     np.testing.assert_allclose(acc.cpu().numpy(), one, rtol=1e-12)
 
 
+@pytest.mark.parametrize("F,P", [(12, 6), (20, 10), (22, 11), (10, 5), (6, 3)], ids=lambda v: str(v))
+def test_gram_family_kernels_flush_at_full_size(F, P):
+    """gram_quadu_kernel (padded pieces: F=12,P=6 with batches of 8 tiles, 20,10 of 4, 22,11 of 2) and
+    gram_small_kernel's dense-load path (10,5 / 6,3) at 4e7 rows: more than 1024 tiles (rows) per wave,
+    so the float32 sums are folded into float64 inside the loop; checked against a float64 product
+    formed in chunks on the device, bitwise reproducible, exact count, symmetric.  The same rows give
+    the solved coefficients' loss through the fused metrics pass: it must equal the closed form
+    y'y - 2 b'X'y + b'X'Xb of the Gram to the float32 rounding of the predictions."""
+    from weather_model_amd import ops
+    n = 40_000_000
+    Xd = ops.synth_uniform((n, F), seed=61)
+    Yd = ops.synth_uniform((n, P), seed=62, lo=-0.02, hi=0.02)
+    bt = torch.from_numpy(np.random.default_rng(F).uniform(-0.5, 0.5, (F + 1, P))).cuda()
+    bt[F] += 1.0
+    step = 2_000_000
+    for s0 in range(0, n, step):
+        Yd[s0:s0 + step] += (Xd[s0:s0 + step].double() @ bt[:F] + bt[F]).float()
+    a = ops.gram(Xd, Yd)
+    assert torch.equal(ops.gram(Xd, Yd), a)                       # bitwise reproducible
+    D = F + 1 + P
+    ref = torch.zeros((D, D), device="cuda", dtype=torch.float64)
+    for s0 in range(0, n, step):
+        Z = torch.cat([Xd[s0:s0 + step].double(),
+                       torch.ones((min(step, n - s0), 1), device="cuda", dtype=torch.float64),
+                       Yd[s0:s0 + step].double()], 1)
+        ref += Z.T @ Z
+    assert a[F, F].item() == n
+    assert relinf(a.cpu().numpy(), ref.cpu().numpy()) < 2e-6
+    assert torch.equal(a, a.T)
+    beta = ops.normal_solve(a, F, P)
+    sums = ops.linear_metrics(Xd, Yd, beta).cpu().numpy()
+    assert sums[3] == n * P
+    r = ref.cpu().numpy()
+    b = beta.cpu().numpy()
+    A = r[:F + 1, :F + 1]
+    B = r[:F + 1, F + 1:]
+    C = r[F + 1:, F + 1:]
+    sse = np.trace(C) - 2.0 * (b * B).sum() + (b * (A @ b)).sum()
+    assert sums[0] == pytest.approx(sse, rel=2e-4)
+
+
 @pytest.mark.parametrize("F,P", [(16, 8), (16, 4), (8, 8)], ids=lambda v: str(v))
 def test_gram_quad_kernel_exact_tails_and_flush(F, P):
     """gram_quad.hip (rows of four equal pieces; eight variables at once = F=16, P=8): exact on
