@@ -352,7 +352,7 @@ def gram_kernel_name(F, P):
         return "gram_small_kernel"
     if (F, P) in ((16, 8), (16, 4), (8, 8)):
         return "gram_quad_kernel"
-    if (F, P) in ((12, 6), (14, 7), (18, 9), (20, 10), (22, 11), (24, 12)):
+    if (P + 3) // 4 <= 3 and (F + 3) // 4 + (P + 3) // 4 <= 9:
         return "gram_quadu_kernel"
     return "gram_mid_kernel" if F + P + 1 <= 64 else "gram_syrk_kernel"
 

@@ -326,15 +326,18 @@ def test_gram_syrk_balanced_schedule_large_n(F, P):
 
 
 @pytest.mark.parametrize("F,P", [(16, 8), (12, 6), (14, 7), (24, 12), (40, 20), (33, 7), (62, 1), (15, 1),
-                                 (18, 9), (20, 10), (22, 11), (32, 16)], ids=lambda v: str(v))
+                                 (18, 9), (20, 10), (22, 11), (32, 16), (32, 1), (9, 1), (28, 3), (25, 5),
+                                 (3, 2), (1, 3), (21, 12)], ids=lambda v: str(v))
 def test_gram_mid_kernel_alignments_and_tails(F, P):
     """gram_mid.hip (15 < F + P, F + P + 1 <= 64): vector-load and dword-load variants, both column
     widths (D <= 32, D <= 64), pointers moved off their 16- / 8-byte alignment, row counts around the
     k-step (4 rows), the in-flight batch and the per-wave ranges; exact on integers, and against the
-    float64 oracle on random rows.  The family F = 2p, P = p for p = 6, 7, 9, 10, 11, 12 (and F=16,P=8
-    off its alignment) now takes gram_quadu_kernel (gram_quad.hip: padded pieces, dword-aligned vector
-    loads that run into the next row, last row read element by element) -- same checks; the row counts
-    below put the last row in a full tile, in a partial one and alone."""
+    float64 oracle on random rows.  Every shape with ceil(F/4) + ceil(P/4) <= 9 and P <= 12 that the
+    narrow-row and the aligned quad kernel leave -- the family F = 2p, P = p for p = 6 .. 12, one target
+    with 9 .. 32 predictors, any of them off its alignment -- now takes gram_quadu_kernel<RX, RY>
+    (gram_quad.hip: padded pieces, dword-aligned vector loads that run into the next row, last row
+    read element by element) -- same checks; the row counts below put the last row in a full tile,
+    in a partial one and alone."""
     from weather_model_amd import ops, synth
     from oracle import cpu as ocpu
     for n in (1, 3, 4, 5, 15, 16, 17, 63, 64, 65, 8191, 8192 * 4 + 3, 2048 * 128, 300_007):

@@ -4,7 +4,8 @@
 //                   multipleRegression shape F = 2, P = 1: multipleRegression.py:35,273-286)
 //   gram_quad.hip   F = 4 RX, P = 4 RY for a few (RX, RY) (eight variables at once: F = 16, P = 8):
 //                   gram_f16's 4x4x1 MFMA scheme with Y as further operand registers, HBM-bound
-//                   (+ gram_quadu_kernel: padded pieces, any alignment -- F = 2p, P = p for p = 6 .. 12)
+//                   (+ gram_quadu_kernel<RX, RY>: padded pieces, any alignment -- F = 2p, P = p for
+//                   p = 6 .. 12, one target with up to 32 predictors, ...)
 //   gram_mid.hip    F + P + 1 <= 64 otherwise: operands straight from global memory into MFMA
 //                   registers, any alignment (the drop-ins' multi-variable fits, F = 2p, P = p)
 //   gram_syrk.hip   every other shape: LDS-staged blocked Z'Z on fp32 MFMA (the reference's
@@ -38,8 +39,8 @@ size_t wm_gram_quad_workspace_bytes(int F, int P);
 int wm_gram_quad_launch(const float *X, const float *Y, long long n, int F, int P, double *acc,
                         double *partial, hipStream_t st);
 
-// A few (F, P) of the family F = 2p, P = p whose rows are not four equal pieces (or whose pointers are
-// not aligned to them), any 4-byte alignment.  Workspace: per-workgroup float64 partials.
+// ceil(F / 4) + ceil(P / 4) <= 9 and P <= 12: rows that are not four equal pieces (or whose pointers
+// are not aligned to them), any 4-byte alignment.  Workspace: per-workgroup float64 partials.
 bool wm_gram_quadu_supported(int F, int P);
 size_t wm_gram_quadu_workspace_bytes(int F, int P);
 int wm_gram_quadu_launch(const float *X, const float *Y, long long n, int F, int P, double *acc,

@@ -202,26 +202,25 @@ __device__ __forceinline__ void qu_load(const float *__restrict__ p, float *__re
     }
 }
 
-template <int F, int P>
+template <int RX_, int RY_>
 struct QuCfg {
-    static constexpr int RX = (F + 3) / 4, RY = (P + 3) / 4, R = RX + RY;
+    static constexpr int RX = RX_, RY = RY_, R = RX + RY;
     static constexpr int NP = R * (R + 1) / 2, NVAL = NP * 4 + R, PART = NVAL * 4;
-    static constexpr bool MASKX = 4 * RX != F, MASKY = 4 * RY != P;
     // tiles per batch: two batches of U (R floats each) beside 4 NP accumulator registers
     static constexpr int U = R <= 6 ? 8 : (R <= 8 ? 4 : 2);
     // beyond R = 9 the 4 NP accumulator registers alone pass 256; F=32,P=16 (R = 12) with one wave per
     // SIMD and 512 registers was tried: 360 VGPRs, no spill reported, 71 ms against gram_mid's 1.9
-    static constexpr int WPS = 2;
     static_assert(R <= 9, "gram_quadu: ceil(F/4) + ceil(P/4) <= 9");
 };
 
-template <int F, int P>
-__global__ __launch_bounds__(BLOCK, (QuCfg<F, P>::WPS)) void gram_quadu_kernel(const float *__restrict__ X,
+// F in (4 RX - 4, 4 RX], P in (4 RY - 4, 4 RY]: one instantiation per (RX, RY), F and P at run time
+template <int RX, int RY>
+__global__ __launch_bounds__(BLOCK, 2) void gram_quadu_kernel(const float *__restrict__ X,
                                                               const float *__restrict__ Y, long long n,
-                                                              double *__restrict__ partial)
+                                                              int F, int P, double *__restrict__ partial)
 {
-    using C = QuCfg<F, P>;
-    constexpr int R = C::R, RX = C::RX, RY = C::RY, NP = C::NP, U = C::U;
+    using C = QuCfg<RX, RY>;
+    constexpr int R = C::R, NP = C::NP, U = C::U;
     __shared__ double red[WAVES][C::NVAL][4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int a = lane & 3, srow = lane >> 2;
@@ -229,7 +228,8 @@ __global__ __launch_bounds__(BLOCK, (QuCfg<F, P>::WPS)) void gram_quadu_kernel(c
     const long long wave_id = (long long)blockIdx.x * WAVES + wv;
     const long long tiles = (n + 15) >> 4;
     // tiles whose vector loads stay inside the arrays: all full tiles but the one holding the last row
-    const long long safe_tiles = (C::MASKX || C::MASKY) ? (n - 1 > 0 ? (n - 1) >> 4 : 0) : (n >> 4);
+    const bool padded = 4 * RX != F || 4 * RY != P;
+    const long long safe_tiles = padded ? (n - 1 > 0 ? (n - 1) >> 4 : 0) : (n >> 4);
     for (int i = lane; i < C::PART; i += 64) (&red[wv][0][0])[i] = 0.0;
     f32x4 g[NP];
     float sz[R];
@@ -244,24 +244,22 @@ __global__ __launch_bounds__(BLOCK, (QuCfg<F, P>::WPS)) void gram_quadu_kernel(c
     for (int r = 0; r < RY; ++r) live[RX + r] = a * RY + r < P;
     const float *__restrict__ xl = X + (long long)srow * F + a * RX;
     const float *__restrict__ yl = Y + (long long)srow * P + a * RY;
+    const long long xstep = 16ll * F, ystep = 16ll * P;           // floats per tile
     int since_flush = 0;
     const long long nb = safe_tiles / U;
     auto fetch = [&](float(&z)[U][R], long long bq) __attribute__((always_inline)) {
         const long long t_ = (bq < nb ? bq : wave_id % (nb > 0 ? nb : 1)) * U;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            qu_load<RX>(xl + (t_ + u) * 16 * F, &z[u][0]);
-            qu_load<RY>(yl + (t_ + u) * 16 * P, &z[u][RX]);
+            qu_load<RX>(xl + (t_ + u) * xstep, &z[u][0]);
+            qu_load<RY>(yl + (t_ + u) * ystep, &z[u][RX]);
         }
     };
     auto consume = [&](float(&z)[U][R]) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if constexpr (C::MASKX || C::MASKY) {
 #pragma unroll
-                for (int r = 0; r < R; ++r)
-                    if ((r < RX && C::MASKX) || (r >= RX && C::MASKY)) z[u][r] = live[r] ? z[u][r] : 0.f;
-            }
+            for (int r = 0; r < R; ++r) z[u][r] = live[r] ? z[u][r] : 0.f;
             q_step_z<R>(g, sz, z[u]);
         }
         since_flush += U;
@@ -397,18 +395,19 @@ int wm_gram_quad_launch(const float *X, const float *Y, long long n, int F, int 
     return WM_OK;
 }
 
-// the padded / unaligned variant: shapes of the family F = 2p, P = p (and their (F, 1) cousins are
-// gram_small's or gram_mid's) that the aligned kernel above does not take
-#define WM_QUADU_SHAPES(X_) X_(12, 6) X_(14, 7) X_(18, 9) X_(20, 10) X_(22, 11) X_(24, 12) X_(16, 8)
+// the padded / unaligned variant: every F, P with ceil(F / 4) + ceil(P / 4) <= 9 and P <= 12 that the
+// narrow-row kernel and the aligned kernel above leave: one instantiation per (RX, RY)
+#define WM_QUADU_RXRY(X_)                                                                        \
+    X_(1, 1) X_(2, 1) X_(3, 1) X_(4, 1) X_(5, 1) X_(6, 1) X_(7, 1) X_(8, 1)                      \
+    X_(1, 2) X_(2, 2) X_(3, 2) X_(4, 2) X_(5, 2) X_(6, 2) X_(7, 2)                               \
+    X_(1, 3) X_(2, 3) X_(3, 3) X_(4, 3) X_(5, 3) X_(6, 3)
 
 bool wm_gram_quadu_supported(int F, int P)
 {
     static const bool off = [] { const char *e = getenv("WM_GRAM_QUADU"); return e && e[0] == '0'; }();
-    if (off) return false;                     // probe switch: A/B against gram_mid
-#define X_(F_, P_) if (F == F_ && P == P_) return true;
-    WM_QUADU_SHAPES(X_)
-#undef X_
-    return false;
+    if (off || F < 1 || P < 1) return false;   // probe switch: A/B against gram_mid
+    const int rx = (F + 3) / 4, ry = (P + 3) / 4;
+    return ry <= 3 && rx + ry <= 9;
 }
 
 size_t wm_gram_quadu_workspace_bytes(int F, int P)
@@ -420,21 +419,22 @@ size_t wm_gram_quadu_workspace_bytes(int F, int P)
 int wm_gram_quadu_launch(const float *X, const float *Y, long long n, int F, int P, double *acc,
                          double *partial, hipStream_t st)
 {
-    int grid = quad_grid();
+    const int grid = quad_grid();
+    const int rx = (F + 3) / 4, ry = (P + 3) / 4;
     bool launched = false;
-#define X_(F_, P_)                                                                               \
-    if (F == F_ && P == P_) {                                                                    \
-        grid = wm_num_cus() * QuCfg<F_, P_>::WPS;                                                \
-        hipLaunchKernelGGL((gram_quadu_kernel<F_, P_>), dim3(grid), dim3(BLOCK), 0, st, X, Y, n, partial); \
+#define X_(RX_, RY_)                                                                             \
+    if (rx == RX_ && ry == RY_) {                                                                \
+        hipLaunchKernelGGL((gram_quadu_kernel<RX_, RY_>), dim3(grid), dim3(BLOCK), 0, st, X, Y, n, F, P, \
+                           partial);                                                             \
         launched = true;                                                                         \
     }
-    WM_QUADU_SHAPES(X_)
+    WM_QUADU_RXRY(X_)
 #undef X_
     WM_REQUIRE(launched, WM_ERR_UNSUPPORTED, "gram_quadu: F=%d P=%d not instantiated", F, P);
     WM_LAUNCH_CHECK("gram_quadu_kernel");
     const int D = F + 1 + P;
     hipLaunchKernelGGL(gram_quad_finalize_kernel, dim3(D * D), dim3(64), 0, st,
-                       (const double *)partial, grid, n, (F + 3) / 4, (P + 3) / 4, F, P, acc);
+                       (const double *)partial, grid, n, rx, ry, F, P, acc);
     WM_LAUNCH_CHECK("gram_quad_finalize_kernel");
     return WM_OK;
 }
