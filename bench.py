@@ -601,7 +601,7 @@ def run_gram64(steps, warmup, rank, world, cpu_base, rows_per_gpu, chunk_rows=50
             X, Y = bufs[c % 2]
             m = min(chunk, rows_per_gpu - c * chunk)
             _lib.check(L.wm_synth_regression_f32(X.data_ptr(), Y.data_ptr(), m, F, P, 1,
-                                                 row_off + c * chunk, bt.data_ptr(), 0.5, 0.01, 2, st))
+                                                 row_off + c * chunk, bt.data_ptr(), 0.5, 0.01, 3, st))
             if timed:
                 e = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 e[0].record()

@@ -132,6 +132,21 @@ def test_device_generator_matches_host_generator():
     u = synth.uniform_paired01(5, 200_000)
     assert 0.0 <= u.min() and u.max() < 1.0 and abs(u.mean() - 0.5) < 5e-3
     assert abs(np.corrcoef(u[0::2], u[1::2])[0, 1]) < 1e-2      # the two draws of a hash
+    # one 32-bit hash per element (dist 3, config 5's generator): same three kernels, plus a row
+    # offset whose element indices cross 2^32 (the high half of the index enters the key)
+    for F, P, off in ((64, 1, 0), (16, 1, 12345), (6, 2, 7), (64, 1, (1 << 32) // 64 - 1500)):
+        beta = synth.normal(1003, (F, P))
+        Xd, Yd = ops.synth_regression(3000, F, P, seed=3, beta=torch.from_numpy(beta), dist="uniform32",
+                                      row_offset=off)
+        Xh, Yh, _ = synth.regression_problem(3000, F, P, seed=3, dist="uniform32", row_offset=off)
+        assert np.array_equal(Xd.cpu().numpy(), Xh)
+        assert np.abs(Yd.cpu().numpy() - Yh).max() < 1e-4
+    u = synth.uniform32_01(5, 400_000)
+    assert 0.0 <= u.min() and u.max() < 1.0 and abs(u.mean() - 0.5) < 3e-3
+    assert abs(u.var() - 1.0 / 12.0) < 1e-3
+    for lag in (1, 2, 3, 4, 64):                                # neighbours in a row, and one row apart
+        assert abs(np.corrcoef(u[:-lag], u[lag:])[0, 1]) < 1e-2
+    assert abs(np.corrcoef(u, synth.uniform32_01(6, 400_000))[0, 1]) < 1e-2      # another seed
 
 
 def test_full_size_property_recovers_planted_coefficients():

@@ -27,6 +27,26 @@ __device__ __forceinline__ float u01_paired(uint64_t seed, uint64_t e)
     return (e & 1) ? u01_lo(z) : u01(z);
 }
 
+// dist 3, "uniform32": one 32-bit hash per element -- two 32-bit multiplies (the lowbias32 finaliser)
+// where a splitmix64 costs eight quarter-rate 32-bit multiply instructions.  The 64-bit element index
+// is folded into the 32-bit key with odd multipliers, so keys stay distinct within any window of 2^32
+// consecutive elements and the high half selects a different sequence.  The row generator of config
+// 5 was thought bound by its integer multiplies; measured 2.6 -> 2.5 ms per 5e7 x 64 chunk against
+// dist 2 -- the 13 GB non-temporal write stream (5.2 TB/s) is the bound by now.
+__device__ __forceinline__ uint32_t key32(uint64_t seed, uint64_t e)
+{
+    return (uint32_t)e + 0x9E3779B9u * (uint32_t)(e >> 32) + 0x85EBCA6Bu * (uint32_t)seed + 0x165667B1u;
+}
+__device__ __forceinline__ float u01_32(uint32_t k)
+{
+    k ^= k >> 16;
+    k *= 0x7FEB352Du;
+    k ^= k >> 15;
+    k *= 0x846CA68Bu;
+    k ^= k >> 16;
+    return (float)(k >> 8) * 0x1.0p-24f;
+}
+
 __device__ __forceinline__ float gauss(uint64_t z)
 {
     const float u1 = ((float)(z >> 40) + 1.0f) * 0x1.0p-24f;            // (0,1]
@@ -55,7 +75,8 @@ __global__ __launch_bounds__(BLOCK) void synth_regression_kernel(
             float s = intercept;
             for (int f = 0; f < F; ++f) {
                 const uint64_t e = gr * (uint64_t)F + f;
-                const float xv = dist == 2 ? u01_paired(seed, e) : (dist ? gauss(hash64(seed, e)) : u01(hash64(seed, e)));
+                const float xv = dist == 3 ? u01_32(key32(seed, e))
+                                 : dist == 2 ? u01_paired(seed, e) : (dist ? gauss(hash64(seed, e)) : u01(hash64(seed, e)));
                 if (p == 0) X[r * F + f] = xv;
                 s = fmaf(xv, beta[f * P + p], s);
             }
@@ -93,7 +114,11 @@ __global__ __launch_bounds__(BLOCK) void synth_regression_rows_kernel(
             const long long r = min(r_, n - 1);       // clamped: every lane takes part in the sum
             const uint64_t e0 = (row_offset + (uint64_t)r) * (uint64_t)F + (uint64_t)(4 * g);
             f32x4 xv;
-            if (dist == 2) {                          // e0 is a multiple of 4: two hashes, four floats
+            if (dist == 3) {                          // e0 is a multiple of 4: e0 .. e0 + 3 share their high half
+                const uint32_t k0 = key32(seed, e0);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) xv[k] = u01_32(k0 + (uint32_t)k);
+            } else if (dist == 2) {                   // two hashes, four floats
                 const uint64_t za = hash64(seed, e0 >> 1), zb = hash64(seed, (e0 >> 1) + 1);
                 xv[0] = u01(za); xv[1] = u01_lo(za); xv[2] = u01(zb); xv[3] = u01_lo(zb);
             } else {

@@ -896,7 +896,7 @@ def synth_uniform(shape, seed, lo=0.0, hi=1.0, offset=0, device="cuda"):
     return out
 
 
-SYNTH_DIST = {"uniform": 0, "normal": 1, "uniform_paired": 2}
+SYNTH_DIST = {"uniform": 0, "normal": 1, "uniform_paired": 2, "uniform32": 3}
 
 
 def synth_regression(n, F, P, seed, beta, intercept=0.5, noise=0.01, dist="uniform",

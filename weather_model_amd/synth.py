@@ -45,6 +45,23 @@ def uniform_paired01(seed: int, count: int, offset: int = 0) -> np.ndarray:
     return bits.astype(np.float32) * np.float32(2.0 ** -24)
 
 
+def uniform32_01(seed: int, count: int, offset: int = 0) -> np.ndarray:
+    """float32 U[0,1) from one 32-bit hash per element (csrc/synth.hip, dist 3): the lowbias32
+    finaliser of a key that folds the 64-bit element index with odd multipliers.  A different
+    stream from uniform01 / uniform_paired01."""
+    idx = np.arange(offset, offset + count, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        k = (idx & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        k = k + np.uint32(0x9E3779B9) * (idx >> np.uint64(32)).astype(np.uint32)
+        k = k + np.uint32(0x85EBCA6B) * np.uint32(int(seed) & 0xFFFFFFFF) + np.uint32(0x165667B1)
+        k ^= k >> np.uint32(16)
+        k *= np.uint32(0x7FEB352D)
+        k ^= k >> np.uint32(15)
+        k *= np.uint32(0x846CA68B)
+        k ^= k >> np.uint32(16)
+    return (k >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24)
+
+
 def uniform(seed: int, shape, lo=0.0, hi=1.0, offset: int = 0) -> np.ndarray:
     n = int(np.prod(shape))
     u = uniform01(seed, n, offset)
@@ -72,6 +89,8 @@ def regression_problem(n: int, F: int, P: int = 1, seed: int = 1, dist: str = "u
         X = uniform(seed, (n, F), offset=row_offset * F)
     elif dist == "uniform_paired":
         X = uniform_paired01(seed, n * F, offset=row_offset * F).reshape(n, F)
+    elif dist == "uniform32":
+        X = uniform32_01(seed, n * F, offset=row_offset * F).reshape(n, F)
     else:
         X = normal(seed, (n, F), offset=row_offset * F)
     eps = normal(seed + 2000, (n, P), std=noise, offset=row_offset * P)
