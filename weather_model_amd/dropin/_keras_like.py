@@ -22,9 +22,11 @@ solver, the ridge used and the parity status so that nobody mistakes the numbers
 trajectory.  There is no CPU path: without libwm.so and a GPU every compute call raises.
 
 Rows never have to fit in memory twice: a generator that can rebuild its batches on the GPU from a
-resident volume (``device_rows``: ``wm_gather_cubes_f32``) is streamed chunk by chunk, once for the
-Gram and once for the metrics; host generators are staged through a pinned buffer and their device
-chunks are kept for the metrics pass only up to ``max_resident_rows``.
+resident volume (``device_rows``: ``wm_gather_cubes_f32``) is streamed chunk by chunk; host
+generators are staged through a pinned buffer.  Either way the device chunks are kept for the
+metrics pass up to ``max_resident_rows`` (and 8 GiB for the gathered ones); beyond that a device
+generator is rewound and gathered again, a host generator's metrics fall back to the loss from the
+Gram.
 
 Parity note: tensorflow/keras are absent from the build container, so nothing here is pinned
 against the reference's own training run ("parity unpinned"); the fit is pinned against float64
@@ -296,18 +298,35 @@ class LinearStackModel:
                 chunk_rows = max(1 << 16, (1 << 30) // (4 * (self.F + self.P)))
             per = max(1, int(chunk_rows) // max(1, int(source.rows_per_batch())))
             state = source.get_state()
+            # the gathered chunks stay resident for the metrics pass while they fit the row budget
+            # and 8 GiB: at scale the gather is 2-3x the Gram or metrics pass it feeds, and until
+            # round 3's last session an epoch gathered every chunk twice
+            kept: list = []
+            budget = {"rows": int(keep_rows_up_to or 0), "bytes": 8 << 30, "ok": bool(keep_rows_up_to)}
 
-            def run(fn):
+            def run(fn, collect=False):
                 left = int(steps)
                 while left > 0:
                     k = min(per, left)
                     X, Y = source.device_rows(k, self.device)
                     fn(X, Y)
+                    if collect and budget["ok"]:
+                        budget["rows"] -= X.shape[0]
+                        budget["bytes"] -= 4 * X.shape[0] * (self.F + self.P)
+                        if budget["rows"] < 0 or budget["bytes"] < 0:
+                            budget["ok"] = False
+                            kept.clear()
+                        else:
+                            kept.append((X, Y))
                     left -= k
-            run(on_chunk)
+            run(on_chunk, collect=True)
             end_state = source.get_state()
 
             def replay(fn):
+                if budget["ok"]:
+                    for X, Y in kept:
+                        fn(X, Y)
+                    return
                 source.set_state(state)
                 run(fn)
                 source.set_state(end_state)
