@@ -8,6 +8,7 @@
 // Algorithmic bytes: stats 4 B/element (read once); normalise 8 B/element; gather 72 B read +
 // 72 B written per sample (6 variables).
 #include "common.h"
+#include "cube_walk.h"
 
 namespace {
 
@@ -269,46 +270,7 @@ __global__ __launch_bounds__(BLOCK) void gather_triplets_u32_kernel(
 //     R0_b = index_b / length,  R1_b = R0_{b-1} / dim_z,  R2_b = R1_{b-1} / dim_y   (b >= 1),
 //     origin = (R0_b % dim_z, R1_b % dim_y, R2_b % dim_x)
 // -- the reference's update rule, including that R1 and R2 lag one and two batches behind.
-struct CubeWalk {
-    long long length, index0, r0, r1, r2;
-    int bs, dim_z, dim_y, dim_x;
-};
-// element strides of the volume's (file, variable, z, y, x) axes: the row-major layout of the
-// reference, or any other resident layout (wm_gather_cubes_strided_f32)
-struct CubeStrides {
-    long long f, v, z, y, x;
-};
-
-// Division by a launch-invariant divisor (Granlund-Montgomery, round-up form): exact for every
-// 32-bit unsigned dividend.  A hardware 32-bit division is ~30 instructions and a 64-bit one ~100;
-// the walk below takes nine per element and the kernel was bound by them (point-major volume,
-// 1 M rows of 8: 95 us with 64-bit divisions, 78 with 32-bit ones; see DESIGN.md for this form).
-struct FastDiv {
-    unsigned d, m, s1, s2;
-};
-__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv &f)
-{
-    const unsigned t = __umulhi(f.m, n);
-    return (t + ((n - t) >> f.s1)) >> f.s2;
-}
-struct CubeDivs {
-    FastDiv p, bs, length, dim_z, dim_y, dim_x, cx, cy, cz;
-};
-
-// walk state of batch b (see the comment above CubeWalk); I = long long, or unsigned-with-FastDiv
-// when every count fits 31 bits
-__device__ __forceinline__ long long walk_r0(const CubeWalk &w, long long b)
-{
-    return b <= 0 ? w.r0 : (w.index0 + b) / w.length;
-}
-__device__ __forceinline__ long long walk_r1(const CubeWalk &w, long long b)
-{
-    return b <= 0 ? w.r1 : walk_r0(w, b - 1) / w.dim_z;
-}
-__device__ __forceinline__ long long walk_r2(const CubeWalk &w, long long b)
-{
-    return b <= 0 ? w.r2 : walk_r1(w, b - 1) / w.dim_y;
-}
+using namespace wm_walk;          // CubeWalk, CubeStrides, FastDiv, CubeDivs, fdiv, walk_r*: cube_walk.h
 
 // VEC = 4: cube 1 with the variables of a point contiguous and 16-byte aligned (the point-major
 // volume): a thread moves four variables per time slice; p, the element count and dv.p are then in
@@ -332,22 +294,7 @@ __global__ __launch_bounds__(BLOCK) void gather_cubes_kernel(
             r = ru;
             q = (int)(eu - ru * (unsigned)p);
             if (!origins) {
-                const unsigned b = fdiv(ru, dv.bs), ib = (unsigned)w.index0 + b;
-                const unsigned R0 = fdiv(ib, dv.length);
-                f = (long long)((ib - R0 * (unsigned)w.length) * (unsigned)w.bs +
-                                (ru - b * (unsigned)w.bs));
-                // R1_b = R0_{b-1} / dim_z, R2_b = (R0_{b-2} / dim_z) / dim_y; raw state for b <= 0
-                const unsigned R0m1 = b >= 1 ? fdiv(ib - 1, dv.length) : 0u;
-                const unsigned R0m2 = b >= 2 ? fdiv(ib - 2, dv.length) : 0u;
-                const unsigned r0 = b == 0 ? (unsigned)w.r0 : R0;
-                const unsigned r1 = b == 0 ? (unsigned)w.r1
-                                           : fdiv(b == 1 ? (unsigned)w.r0 : R0m1, dv.dim_z);
-                const unsigned r1m1 = b <= 1 ? (unsigned)w.r1
-                                             : fdiv(b == 2 ? (unsigned)w.r0 : R0m2, dv.dim_z);
-                const unsigned r2 = b == 0 ? (unsigned)w.r2 : fdiv(r1m1, dv.dim_y);
-                z0 = (int)(r0 - fdiv(r0, dv.dim_z) * (unsigned)w.dim_z);
-                y0 = (int)(r1 - fdiv(r1, dv.dim_y) * (unsigned)w.dim_y);
-                x0 = (int)(r2 - fdiv(r2, dv.dim_x) * (unsigned)w.dim_x);
+                decode_small(ru, w, dv, f, z0, y0, x0);
             }
         } else {
             r = e / p;
@@ -403,15 +350,6 @@ __global__ __launch_bounds__(BLOCK) void gather_cubes_kernel(
             yout[r * p + o] = src[d_mid * st.f];
         }
     }
-}
-
-FastDiv fast_div(unsigned d)
-{
-    // l = ceil(log2 d); m = floor(2^32 (2^l - d) / d) + 1; q = (t + ((n - t) >> min(l,1))) >> max(l-1,0)
-    unsigned l = 0;
-    while (l < 32 && (1ull << l) < d) ++l;
-    const unsigned long long m = ((1ull << 32) * ((1ull << l) - d)) / d + 1;
-    return {d, (unsigned)m, l < 1 ? l : 1u, l > 0 ? l - 1 : 0u};
 }
 
 int stream_grid(long long work_items, int per_cu = 8)
