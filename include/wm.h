@@ -349,6 +349,28 @@ int wm_gather_cubes_strided_f32(const float *vol, int files, int nvars, int Z, i
                                 float *x1out, float *x2out, int64_t xstride, float *yout,
                                 void *stream);
 
+/* The Gram of the rows that wm_gather_cubes_strided_f32 would build -- [x(t) | x(t + d_end)] ;
+ * x(t + d_mid) along the region walk of WeatherDataGenerator (multipleRegression.py:217-270) -- read
+ * STRAIGHT from the resident volume: no X, no Y, one pass.  CUBE_SIZE 1 (the reference's setting,
+ * multipleRegression.py:35) and 1..4 variables (F = 2 nvars, P = nvars; WM_ERR_UNSUPPORTED
+ * otherwise: gather the rows and call wm_gram_f32).  `strides` are the element strides of the
+ * volume's (file, variable, z, y, x) axes; the walk arguments are those of wm_gather_cubes_f32.
+ * acc is the (F+1+P)^2 float64 accumulator of wm_gram_f32 (same entries, same fixed-order float64
+ * combination, bitwise reproducible; a different summation order than gather + wm_gram_f32).
+ * wm_linear_metrics_walk_f32 is the matching loss / mae / msle pass (see wm_linear_metrics_f32). */
+size_t wm_gram_walk_workspace_bytes(int nvars);
+int wm_gram_walk_f32(const float *vol, int files, int nvars, int Z, int Y, int X,
+                     const int64_t *strides, int d_mid, int d_end, int64_t rows, int batch,
+                     int64_t length, int64_t index0, int64_t r0, int64_t r1, int64_t r2, int dim_z,
+                     int dim_y, int dim_x, double *acc, void *workspace, size_t workspace_bytes,
+                     void *stream);
+int wm_linear_metrics_walk_f32(const float *vol, int files, int nvars, int Z, int Y, int X,
+                               const int64_t *strides, int d_mid, int d_end, int64_t rows, int batch,
+                               int64_t length, int64_t index0, int64_t r0, int64_t r1, int64_t r2,
+                               int dim_z, int dim_y, int dim_x, const double *beta, int want_msle,
+                               float msle_eps, double *sums, void *workspace, size_t workspace_bytes,
+                               void *stream);
+
 /* The Dense layers of the Conv3D model (convolution.py:175-176: Dense(flat, relu), Dense(prod(
  * input_shape))) and their gradients, replacing keras.layers.Dense / its autodiff for the batch
  * sizes the reference trains with.  x is (M, K), W is (N, K) = (units, inputs), b is (N) or NULL,

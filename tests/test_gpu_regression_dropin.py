@@ -308,6 +308,69 @@ def test_gather_cubes_point_major_view_matches_row_major():
         assert all(torch.equal(u, v) for u, v in zip(a, b))
 
 
+def test_gram_and_metrics_straight_from_the_volume_match_the_gathered_rows():
+    """wm_gram_walk_f32 / wm_linear_metrics_walk_f32 (CUBE_SIZE 1, 1..4 variables) against the
+    gathered rows through wm_gram_f32 / wm_linear_metrics_f32: integer data -> the Gram is exact
+    (every product and sum is an integer below 2^24 per float32 partial); random data -> 2e-6
+    relative (float32 partial sums in another order); the metrics' predictions are the same bits per
+    row, their squares are summed in float32 groups of up to 8 outputs before the float64 sums, and the
+    groups differ (2e-6 relative).  Row-major and point-major volumes, walks that
+    start mid-state, row counts that are not whole batches / trips, accumulation into a used acc."""
+    from weather_model_amd import _lib, ops
+    g = torch.Generator().manual_seed(3)
+    for nv, bs, rows_extra, index, region in ((1, 16, 0, 0, (0, 0, 0)), (2, 5, 3, 3, (1, 0, 0)),
+                                              (3, 7, 0, 11, (5, 2, 1)), (4, 16, 9, 2, (0, 1, 0))):
+        files, Z, Y, X = 70, 3, 4, 5
+        ints = torch.randint(0, 8, (files, nv, Z, Y, X), generator=g).float()
+        rnd = torch.rand((files, nv, Z, Y, X), generator=g)
+        length = (files - 6) // bs
+        walk = {"batch": bs, "length": length, "index": index, "region": region, "dims": (Z, Y, X)}
+        rows = bs * (9 * length + 1) + rows_extra
+        for host, exact in ((ints, True), (rnd, False)):
+            rowmajor = host.cuda()
+            stored = host.permute(2, 3, 4, 0, 1).contiguous().cuda()
+            view = stored.permute(3, 4, 0, 1, 2)
+            Xr, Yr = ops.gather_cubes(rowmajor, (1, 1, 1), 3, 6, rows, walk=walk)
+            want = ops.gram(Xr, Yr)
+            for vol in (rowmajor, view):
+                assert ops.walk_fused_supported(vol, (1, 1, 1))
+                got = ops.gram_walk(vol, 3, 6, rows, walk)
+                if exact:
+                    assert torch.equal(got, want)
+                else:
+                    assert torch.allclose(got, want, rtol=2e-6, atol=0)
+                again = ops.gram_walk(vol, 3, 6, rows, walk, acc=got.clone())
+                assert torch.allclose(again, 2 * want, rtol=2e-6, atol=0)
+            beta = torch.rand((2 * nv + 1, nv), generator=g, dtype=torch.float64).cuda() / (2 * nv)
+            for msle in (True, False):
+                ws = ops.linear_metrics(Xr, Yr, beta, want_msle=msle)
+                for vol in (rowmajor, view):
+                    gs = ops.linear_metrics_walk(vol, 3, 6, rows, walk, beta, want_msle=msle)
+                    assert gs[3].item() == rows * nv
+                    assert torch.allclose(gs, ws, rtol=2e-6, atol=0)
+    # big enough for several trips of the whole grid, point-major
+    files, nv, Z, Y, X = 2100, 1, 6, 10, 10
+    host = torch.rand((files, nv, Z, Y, X), generator=g)
+    view = host.permute(2, 3, 4, 0, 1).contiguous().cuda().permute(3, 4, 0, 1, 2)
+    walk = {"batch": 64, "length": (files - 6) // 64, "index": 0, "region": (0, 0, 0), "dims": (Z, Y, X)}
+    rows = 64 * walk["length"] * Z * Y * X - 17
+    Xr, Yr = ops.gather_cubes(view, (1, 1, 1), 3, 6, rows, walk=walk)
+    assert torch.allclose(ops.gram_walk(view, 3, 6, rows, walk), ops.gram(Xr, Yr), rtol=2e-6, atol=0)
+    beta = torch.tensor([[0.3], [0.6], [0.05]], dtype=torch.float64).cuda()
+    assert torch.allclose(ops.linear_metrics_walk(view, 3, 6, rows, walk, beta),
+                          ops.linear_metrics(Xr, Yr, beta), rtol=2e-6, atol=0)
+    # what it does not take
+    assert not ops.walk_fused_supported(torch.zeros((8, 5, 2, 2, 2), device="cuda"), (1, 1, 1))
+    assert not ops.walk_fused_supported(view, (2, 2, 2))
+    with pytest.raises(_lib.WmError, match="1..4 variables"):
+        ops.gram_walk(torch.zeros((80, 5, 2, 2, 2), device="cuda"), 3, 6, 16,
+                      {"batch": 16, "length": 4, "index": 0, "region": (0, 0, 0), "dims": (2, 2, 2)})
+    with pytest.raises(_lib.WmError, match="resident files"):
+        ops.gram_walk(view[:60], 3, 6, 16,
+                      {"batch": 16, "length": 4, "index": 0, "region": (0, 0, 0), "dims": (2, 2, 2)})
+    assert ops.gram_walk(view, 3, 6, 0, walk).abs().sum().item() == 0
+
+
 def test_fit_without_resident_rows_reports_gram_loss():
     """Rows beyond max_resident_rows are not kept: the loss then comes from the Gram itself
     (MSE = (Y'Y - 2 b'Z'Y + b'Z'Zb) / nP) and agrees with the row-based loss."""

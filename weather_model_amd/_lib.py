@@ -68,6 +68,12 @@ SIGNATURES = {
     "wm_gather_cubes_strided_f32": (c_int, [vp] + [c_int] * 5 + [vp] + [c_int] * 5 + [vp, c_i64, c_int,
                                             c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_int,
                                             vp, vp, c_i64, vp, vp]),
+    "wm_gram_walk_workspace_bytes": (c_sz, [c_int]),
+    "wm_gram_walk_f32": (c_int, [vp] + [c_int] * 5 + [vp, c_int, c_int, c_i64, c_int, c_i64, c_i64, c_i64,
+                                 c_i64, c_i64, c_int, c_int, c_int, vp, vp, c_sz, vp]),
+    "wm_linear_metrics_walk_f32": (c_int, [vp] + [c_int] * 5 + [vp, c_int, c_int, c_i64, c_int, c_i64,
+                                           c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_int, vp, c_int,
+                                           c_f32, vp, vp, c_sz, vp]),
     "wm_dense_fwd_f32": (c_int, [vp, vp, vp, vp, c_int, c_int, c_int, c_int, vp]),
     "wm_dense_bwd_workspace_bytes": (c_sz, [c_int, c_int, c_int]),
     "wm_dense_bwd_f32": (c_int, [vp, vp, vp, vp, vp, vp, vp, vp, c_sz, c_int, c_int, c_int, vp]),

@@ -71,6 +71,103 @@ __device__ __forceinline__ void decode_small(unsigned ru, const CubeWalk &w, con
     x0 = (int)(r2 - fdiv(r2, dv.dim_x) * (unsigned)w.dim_x);
 }
 
+// Kernels that read their rows straight from the volume give a wave a CHUNK of consecutive rows
+// (row = chunk start + 64 u + lane).  decode_small costs ~130 vector instructions per row and bound
+// the first version of those kernels (6.8e7 rows of one variable: 0.30 ms where the loads need
+// 0.06); decoding once per 64 rows in the scalar unit still left ~50 scalar instructions per 64 rows
+// on the CU's one scalar ALU (0.20 ms).  The rows of a chunk share their grid cell unless the chunk
+// straddles the start of a pass over the files (the region state moves there, and reaches y and x one
+// and two batches late): the cell then comes from the chunk's FIRST row alone -- wave-uniform
+// arithmetic, once per chunk -- and a row adds its file.  The per-row decode stays for the few chunks
+// at a pass boundary and for the walk's first three batches (raw start state).
+struct WalkChunk {
+    bool fast;              // one cell for the whole chunk
+    unsigned f0;            // file of the chunk's first row
+    long long cell;         // element offset of the cell (z, y, x part)
+};
+
+// base: first row of the chunk (wave-uniform, < rows); count: rows of a chunk
+__device__ __forceinline__ WalkChunk walk_chunk(unsigned base, unsigned count, long long rows, int Z, int Y,
+                                                int X, const CubeWalk &w, const CubeStrides &st,
+                                                const CubeDivs &dv)
+{
+    base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+    const unsigned last = base + count - 1u < (unsigned)rows ? base + count - 1u : (unsigned)rows - 1u;
+    const unsigned bs = (unsigned)w.bs, len = (unsigned)w.length;
+    const unsigned b0 = fdiv(base, dv.bs), b1 = fdiv(last, dv.bs);
+    const unsigned ib = (unsigned)w.index0 + b0;
+    const unsigned R0 = fdiv(ib, dv.length);
+    const unsigned pos = ib - R0 * len;                                   // batch within the pass
+    WalkChunk c;
+    // batches pos-2 .. pos+(b1-b0) lie in one pass: R0_b = R0_{b-1} = R0_{b-2} for every row
+    c.fast = b0 >= 3u && pos >= 2u && pos + (b1 - b0) < len;
+    const unsigned r1 = fdiv(R0, dv.dim_z), r2 = fdiv(r1, dv.dim_y);
+    int z0 = (int)(R0 - r1 * (unsigned)w.dim_z);
+    int y0 = (int)(r1 - r2 * (unsigned)w.dim_y);
+    int x0 = (int)(r2 - fdiv(r2, dv.dim_x) * (unsigned)w.dim_x);
+    z0 = max(0, min(z0, Z - 1));
+    y0 = max(0, min(y0, Y - 1));
+    x0 = max(0, min(x0, X - 1));
+    c.f0 = pos * bs + (base - b0 * bs);
+    c.cell = z0 * st.z + y0 * st.y + x0 * st.x;
+    return c;
+}
+
+// Where row r = chunk start + k (k = 64 u + lane) starts in the volume: the value of variable 0 at
+// x(t).  Rows past the end get a clamped, valid address and ok = false.
+__device__ __forceinline__ const float *walk_chunk_row(const WalkChunk &c, const float *__restrict__ vol,
+                                                       long long r, unsigned k, long long rows, int files,
+                                                       int Z, int Y, int X, int dmax, const CubeWalk &w,
+                                                       const CubeStrides &st, const CubeDivs &dv, bool &ok)
+{
+    ok = r < rows;
+    if (c.fast) {                                                         // wave-uniform branch
+        const unsigned fmax = (unsigned)(files - 1 - dmax);
+        const unsigned f = c.f0 + k < fmax ? c.f0 + k : fmax;
+        return vol + c.cell + (long long)f * st.f;
+    }
+    long long f;
+    int z0, y0, x0;
+    decode_small((unsigned)(ok ? r : rows - 1), w, dv, f, z0, y0, x0);
+    // the host validated the ranges; clamping keeps a bad walk from faulting the GPU
+    f = max(0ll, min(f, (long long)files - 1 - dmax));
+    z0 = max(0, min(z0, Z - 1));
+    y0 = max(0, min(y0, Y - 1));
+    x0 = max(0, min(x0, X - 1));
+    return vol + (f * st.f + z0 * st.z + y0 * st.y + x0 * st.x);
+}
+
+// One row's 3 V values: a = x(t), c = x(t + d_end), m = x(t + d_mid).  VEC: the V variables of a point
+// are adjacent and aligned (st.v == 1; the host checks the rest) -- one load per time instead of V.
+template <int V, bool VEC>
+__device__ __forceinline__ void walk_load(const float *__restrict__ src, const CubeStrides &st, int d_mid,
+                                          int d_end, float (&a)[V], float (&c)[V], float (&m)[V])
+{
+    if constexpr (VEC && (V == 2 || V == 4)) {
+        typedef float vec __attribute__((ext_vector_type(V)));
+        const vec va = *reinterpret_cast<const vec *>(src);
+        const vec vc = *reinterpret_cast<const vec *>(src + d_end * st.f);
+        const vec vm = *reinterpret_cast<const vec *>(src + d_mid * st.f);
+#pragma unroll
+        for (int v = 0; v < V; ++v) { a[v] = va[v]; c[v] = vc[v]; m[v] = vm[v]; }
+    } else {
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            a[v] = src[v * st.v];
+            c[v] = src[d_end * st.f + v * st.v];
+            m[v] = src[d_mid * st.f + v * st.v];
+        }
+    }
+}
+
+// host: may walk_load<V, true> be used?
+inline bool walk_vec_ok(const float *vol, int V, const CubeStrides &st)
+{
+    if (V != 2 && V != 4) return false;
+    return st.v == 1 && st.f % V == 0 && st.z % V == 0 && st.y % V == 0 && st.x % V == 0 &&
+           ((uintptr_t)vol & (uintptr_t)(4 * V - 1)) == 0;
+}
+
 // l = ceil(log2 d); m = floor(2^32 (2^l - d) / d) + 1; q = (t + ((n - t) >> min(l,1))) >> max(l-1,0)
 inline FastDiv fast_div(unsigned d)
 {
@@ -81,3 +178,11 @@ inline FastDiv fast_div(unsigned d)
 }
 
 }  // namespace wm_walk
+
+// Validates a CUBE_SIZE-1 walk over a resident volume with 1..4 variables and fills the launch
+// structs (gram_small.hip); returns WM_OK or a negative WM_ERR_* with the thread's error text set.
+int wm_walk_setup(const char *who, const float *vol, int files, int nvars, int Z, int Y, int X,
+                  const int64_t *strides, int cz, int cy, int cx, int d_mid, int d_end, int64_t rows,
+                  int batch, int64_t length, int64_t index0, int64_t r0, int64_t r1, int64_t r2,
+                  int dim_z, int dim_y, int dim_x, wm_walk::CubeWalk *w, wm_walk::CubeStrides *cs,
+                  wm_walk::CubeDivs *dv);

@@ -17,6 +17,7 @@
 //     partials, fixed-order finalize (bitwise reproducible).
 #include "gram_internal.h"
 #include "small_stream.h"
+#include "cube_walk.h"
 
 namespace {
 
@@ -179,6 +180,81 @@ __global__ __launch_bounds__(BLOCK, (SmallCfg<F, P>::WPS)) void gram_small_kerne
     }
 }
 
+// ---- rows straight from the resident volume (wm_gram_walk_f32).  The drop-ins' fit used to gather
+// every row [x(t) | x(t + d_end)] ; x(t + d_mid) of the region walk into X and Y (wm_gather_cubes_f32:
+// 12 B read + 12 B written per row at one variable) and then read them back here -- at scale the
+// gather was 2-3x the Gram pass it fed.  With CUBE_SIZE 1 (the reference's setting,
+// multipleRegression.py:35) a row is three values per variable of ONE grid cell, and consecutive rows
+// of a batch are consecutive files: lane = row decodes (file, cell) from the walk's closed form
+// (cube_walk.h: nine multiply-shift divisions), loads its 3 V values from the volume -- neighbours in
+// a wave read neighbouring files, and every value is fetched from HBM once for the three rows that
+// use it -- and accumulates exactly as gram_small_kernel does.  V <= 4 variables (F = 2 V, P = V).
+// The loop is bound by the latency of its loads (a trip's loads, then its arithmetic): rows per lane
+// and trip (UR) and resident waves per SIMD (WPS) are what keep bytes in flight.
+template <int V>
+struct WalkCfg {
+    static constexpr int UR = V == 1 ? 8 : 4;
+    static constexpr int WPS = V <= 2 ? 4 : 2;
+};
+
+template <int V, bool VEC>
+__global__ __launch_bounds__(BLOCK, WalkCfg<V>::WPS) void gram_walk_kernel(
+    const float *__restrict__ vol, int files, int Z, int Y, int X, int d_mid, int d_end, long long rows,
+    wm_walk::CubeWalk w, wm_walk::CubeStrides st, wm_walk::CubeDivs dv, double *__restrict__ partial)
+{
+    constexpr int F = 2 * V, P = V, UR = WalkCfg<V>::UR, CHUNK = 64 * UR;
+    using C = SmallCfg<F, P>;
+    __shared__ double red[WAVES][C::TOT * 64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long nwaves = (long long)gridDim.x * WAVES;
+    const long long wave_id = (long long)blockIdx.x * WAVES + wv;
+    float acc[C::NV];
+#pragma unroll
+    for (int v = 0; v < C::NV; ++v) acc[v] = 0.f;
+    double tot[C::TOT];
+#pragma unroll
+    for (int s = 0; s < C::TOT; ++s) tot[s] = 0.0;
+    int since = 0;
+    const int dmax = d_mid > d_end ? d_mid : d_end;
+    const long long nchunks = (rows + CHUNK - 1) / CHUNK;
+    for (long long ch = wave_id; ch < nchunks; ch += nwaves) {
+        const long long c0 = ch * CHUNK;
+        const wm_walk::WalkChunk wc = wm_walk::walk_chunk((unsigned)c0, CHUNK, rows, Z, Y, X, w, st, dv);
+        float z[UR][C::M];
+#pragma unroll
+        for (int u = 0; u < UR; ++u) {
+            bool ok;
+            const float *src = wm_walk::walk_chunk_row(wc, vol, c0 + u * 64 + lane, (unsigned)(u * 64 + lane),
+                                                       rows, files, Z, Y, X, dmax, w, st, dv, ok);
+            float a[V], c[V], m[V];
+            wm_walk::walk_load<V, VEC>(src, st, d_mid, d_end, a, c, m);
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                z[u][v] = ok ? a[v] : 0.f;
+                z[u][V + v] = ok ? c[v] : 0.f;
+                z[u][2 * V + v] = ok ? m[v] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UR; ++u) small_row<F, P>(acc, z[u]);
+        since += UR;
+        if (since + UR > SM_FLUSH_ROWS) {
+            small_flush<F, P>(acc, tot, lane);
+            since = 0;
+        }
+    }
+    small_flush<F, P>(acc, tot, lane);
+#pragma unroll
+    for (int s = 0; s < C::TOT; ++s) red[wv][s * 64 + lane] = tot[s];
+    __syncthreads();
+    for (int v = threadIdx.x; v < C::NV; v += BLOCK) {
+        double s = 0.0;
+#pragma unroll
+        for (int w2 = 0; w2 < WAVES; ++w2) s += red[w2][v];
+        partial[(size_t)blockIdx.x * C::NV + v] = s;
+    }
+}
+
 // acc (D x D) += fixed-order sum of the per-workgroup partials.  One wave per acc entry.
 __global__ __launch_bounds__(64) void gram_small_finalize_kernel(const double *__restrict__ partial,
                                                                  int nparts, int F, int P,
@@ -247,6 +323,98 @@ int wm_gram_small_launch(const float *X, const float *Y, long long n, int F, int
     const int D = F + 1 + P;
     hipLaunchKernelGGL(gram_small_finalize_kernel, dim3(D * D), dim3(64), 0, st, partial, grid, F,
                        P, n, acc);
+    WM_LAUNCH_CHECK("gram_small_finalize_kernel");
+    return WM_OK;
+}
+
+// ---- the walk's host side, shared with the metrics kernel (linmetrics.hip)
+int wm_walk_setup(const char *who, const float *vol, int files, int nvars, int Z, int Y, int X,
+                  const int64_t *strides, int cz, int cy, int cx, int d_mid, int d_end, int64_t rows,
+                  int batch, int64_t length, int64_t index0, int64_t r0, int64_t r1, int64_t r2,
+                  int dim_z, int dim_y, int dim_x, wm_walk::CubeWalk *w, wm_walk::CubeStrides *cs,
+                  wm_walk::CubeDivs *dv)
+{
+    WM_REQUIRE(vol && strides, WM_ERR_INVALID, "%s: null pointer", who);
+    for (int a = 0; a < 5; ++a)
+        WM_REQUIRE(strides[a] >= 0, WM_ERR_INVALID, "%s: negative stride %lld", who, (long long)strides[a]);
+    WM_REQUIRE(files > 0 && nvars >= 1 && nvars <= 4 && Z > 0 && Y > 0 && X > 0, WM_ERR_UNSUPPORTED,
+               "%s: 1..4 variables are implemented (nvars=%d): gather the rows with "
+               "wm_gather_cubes_f32 and use wm_gram_f32 / wm_linear_metrics_f32", who, nvars);
+    WM_REQUIRE(cz == 1 && cy == 1 && cx == 1, WM_ERR_UNSUPPORTED,
+               "%s: CUBE_SIZE 1 is implemented (cube %d,%d,%d)", who, cz, cy, cx);
+    WM_REQUIRE(d_mid >= 0 && d_end >= 0 && d_mid < files && d_end < files, WM_ERR_INVALID,
+               "%s: file offsets (%d, %d) outside %d files", who, d_mid, d_end, files);
+    WM_REQUIRE(rows >= 0 && batch > 0 && length > 0 && index0 >= 0 && r0 >= 0 && r1 >= 0 && r2 >= 0,
+               WM_ERR_INVALID, "%s: bad walk state", who);
+    WM_REQUIRE(dim_z > 0 && dim_y > 0 && dim_x > 0 && dim_z <= Z && dim_y <= Y && dim_x <= X,
+               WM_ERR_INVALID, "%s: walk region (%d,%d,%d) leaves the grid", who, dim_z, dim_y, dim_x);
+    const int dmax = d_mid > d_end ? d_mid : d_end;
+    WM_REQUIRE((length - 1) * batch + batch - 1 + dmax < files, WM_ERR_INVALID,
+               "%s: walk of %lld batches of %d files + offset %d needs more than the %d resident files",
+               who, (long long)length, batch, dmax, files);
+    const long long lim = 1ll << 31;
+    const long long last_b = index0 + rows / batch + 2;
+    WM_REQUIRE(rows < lim && last_b < lim && length < lim && r0 < lim && r1 < lim && r2 < lim &&
+                   (length + 1) * batch < lim,
+               WM_ERR_UNSUPPORTED, "%s: walk counts beyond 2^31 (gather in pieces instead)", who);
+    *w = {length, index0, r0, r1, r2, batch, dim_z, dim_y, dim_x};
+    *cs = {strides[0], strides[1], strides[2], strides[3], strides[4]};
+    *dv = {wm_walk::fast_div(1u), wm_walk::fast_div((unsigned)batch), wm_walk::fast_div((unsigned)length),
+           wm_walk::fast_div((unsigned)dim_z), wm_walk::fast_div((unsigned)dim_y),
+           wm_walk::fast_div((unsigned)dim_x), wm_walk::fast_div(1u), wm_walk::fast_div(1u),
+           wm_walk::fast_div(1u)};
+    return WM_OK;
+}
+
+extern "C" size_t wm_gram_walk_workspace_bytes(int nvars)
+{
+    if (nvars < 1 || nvars > 4 || wm_num_cus() <= 0) return 0;
+    const int M = 3 * nvars;
+    return (size_t)wm_num_cus() * 4 * (M * (M + 1) / 2 + M) * sizeof(double);     // WalkCfg::WPS <= 4
+}
+
+extern "C" int wm_gram_walk_f32(const float *vol, int files, int nvars, int Z, int Y, int X,
+                                const int64_t *strides, int d_mid, int d_end, int64_t rows, int batch,
+                                int64_t length, int64_t index0, int64_t r0, int64_t r1, int64_t r2,
+                                int dim_z, int dim_y, int dim_x, double *acc, void *workspace,
+                                size_t workspace_bytes, void *stream)
+{
+    wm_walk::CubeWalk w;
+    wm_walk::CubeStrides cs;
+    wm_walk::CubeDivs dv;
+    const int rc = wm_walk_setup("wm_gram_walk_f32", vol, files, nvars, Z, Y, X, strides, 1, 1, 1, d_mid,
+                                 d_end, rows, batch, length, index0, r0, r1, r2, dim_z, dim_y, dim_x, &w,
+                                 &cs, &dv);
+    if (rc) return rc;
+    WM_REQUIRE(acc, WM_ERR_INVALID, "wm_gram_walk_f32: null accumulator");
+    if (rows == 0) return WM_OK;
+    WM_REQUIRE(wm_num_cus() > 0, WM_ERR_NO_DEVICE, "wm_gram_walk_f32: no HIP device");
+    WM_REQUIRE(workspace && workspace_bytes >= wm_gram_walk_workspace_bytes(nvars), WM_ERR_WORKSPACE,
+               "wm_gram_walk_f32: workspace of %zu bytes needed, %zu given",
+               wm_gram_walk_workspace_bytes(nvars), workspace_bytes);
+    hipStream_t st = (hipStream_t)stream;
+    double *partial = (double *)workspace;
+    int grid = 0;                            // every workgroup resident (launch bounds)
+    const bool vec = wm_walk::walk_vec_ok(vol, nvars, cs);
+#define WM_WALK(V_)                                                                              \
+    grid = wm_num_cus() * WalkCfg<V_>::WPS;                                                      \
+    if (vec)                                                                                     \
+        hipLaunchKernelGGL((gram_walk_kernel<V_, true>), dim3(grid), dim3(BLOCK), 0, st, vol, files, Z, Y, \
+                           X, d_mid, d_end, (long long)rows, w, cs, dv, partial);                \
+    else                                                                                         \
+        hipLaunchKernelGGL((gram_walk_kernel<V_, false>), dim3(grid), dim3(BLOCK), 0, st, vol, files, Z,  \
+                           Y, X, d_mid, d_end, (long long)rows, w, cs, dv, partial)
+    switch (nvars) {
+    case 1: WM_WALK(1); break;
+    case 2: WM_WALK(2); break;
+    case 3: WM_WALK(3); break;
+    default: WM_WALK(4); break;
+    }
+#undef WM_WALK
+    WM_LAUNCH_CHECK("gram_walk_kernel");
+    const int F = 2 * nvars, P = nvars, D = F + 1 + P;
+    hipLaunchKernelGGL(gram_small_finalize_kernel, dim3(D * D), dim3(64), 0, st, (const double *)partial,
+                       grid, F, P, (long long)rows, acc);
     WM_LAUNCH_CHECK("gram_small_finalize_kernel");
     return WM_OK;
 }

@@ -16,6 +16,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "cube_walk.h"
 #include "small_stream.h"
 
 namespace {
@@ -1037,6 +1038,63 @@ __global__ __launch_bounds__(BLOCK, 2) void linear_metrics_wide_kernel(
     if (RESID && MSLE && !REDO && !(smax <= 0.2f)) *far_flag = 1;
 }
 
+// ---- rows straight from the resident volume (wm_linear_metrics_walk_f32): the metrics pass beside
+// gram_walk_kernel (gram_small.hip, which has the reasoning).  lane = row of the region walk; the row's
+// 3 V values come from the volume, the predictions and residual sums are lm_small_row's (float64 dot
+// product, intercept first, then [x(t) | x(t + d_end)] in order): the same bits per row as gathering
+// the rows and calling wm_linear_metrics_f32.
+template <int V>
+struct LmWalkCfg {                         // latency-bound loop: rows per lane and trip, waves per SIMD
+    static constexpr int UR = V == 1 ? 8 : 4;
+    static constexpr int WPS = V <= 2 ? 4 : 2;
+};
+
+template <int V, bool MSLE, bool VEC>
+__global__ __launch_bounds__(BLOCK, LmWalkCfg<V>::WPS) void linear_metrics_walk_kernel(
+    const float *__restrict__ vol, int files, int Z, int Y, int X, int d_mid, int d_end, long long rows,
+    wm_walk::CubeWalk w, wm_walk::CubeStrides st, wm_walk::CubeDivs dv, const double *__restrict__ beta,
+    float eps, double *__restrict__ partial)
+{
+    constexpr int F = 2 * V, P = V, LM_WALK_UR = LmWalkCfg<V>::UR, CHUNK = 64 * LM_WALK_UR;
+    const int lane = threadIdx.x & 63;
+    const long long nwaves = (long long)gridDim.x * (BLOCK / 64);
+    const long long wave_id = (long long)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    const int dmax = d_mid > d_end ? d_mid : d_end;
+    double sse = 0.0, sae = 0.0, sle = 0.0;
+    const long long nchunks = (rows + CHUNK - 1) / CHUNK;
+    for (long long ch = wave_id; ch < nchunks; ch += nwaves) {
+        const long long c0 = ch * CHUNK;
+        const wm_walk::WalkChunk wc = wm_walk::walk_chunk((unsigned)c0, CHUNK, rows, Z, Y, X, w, st, dv);
+        float x[LM_WALK_UR][F], y[LM_WALK_UR * P], pred[LM_WALK_UR * P];
+        bool ok[LM_WALK_UR];
+#pragma unroll
+        for (int u = 0; u < LM_WALK_UR; ++u) {
+            const float *src = wm_walk::walk_chunk_row(wc, vol, c0 + u * 64 + lane, (unsigned)(u * 64 + lane),
+                                                       rows, files, Z, Y, X, dmax, w, st, dv, ok[u]);
+            float a[V], c[V], m[V];
+            wm_walk::walk_load<V, VEC>(src, st, d_mid, d_end, a, c, m);
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                x[u][v] = a[v];
+                x[u][V + v] = c[v];
+                y[u * P + v] = m[v];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < LM_WALK_UR; ++u) {
+            lm_small_predict<F, P>(x[u], beta, pred + u * P);
+            // a row past the end scores prediction 0 against target 0: nothing in any of the sums
+#pragma unroll
+            for (int v = 0; v < P; ++v) {
+                pred[u * P + v] = ok[u] ? pred[u * P + v] : 0.f;
+                y[u * P + v] = ok[u] ? y[u * P + v] : 0.f;
+            }
+        }
+        lm_resid_groups<0, LM_WALK_UR * P, MSLE>(pred, y, eps, sse, sae, sle);
+    }
+    lm_block_out(sse, sae, sle, partial);
+}
+
 int lw_tiles(int P) { return P <= 64 ? 4 : P <= 128 ? 8 : 14; }
 
 __global__ __launch_bounds__(BLOCK) void residual_sums_kernel(const float *__restrict__ pred,
@@ -1272,6 +1330,62 @@ extern "C" int wm_linear_metrics_f32(const float *X, const float *Y, const doubl
     WM_LAUNCH_CHECK("linear_metrics_kernel");
     hipLaunchKernelGGL(metrics_finish_kernel, dim3(3), dim3(BLOCK), 0, st, (const double *)partial, grid,
                        (double)n * (double)P, sums);
+    WM_LAUNCH_CHECK("metrics_finish_kernel");
+    return WM_OK;
+}
+
+extern "C" int wm_linear_metrics_walk_f32(const float *vol, int files, int nvars, int Z, int Y, int X,
+                                          const int64_t *strides, int d_mid, int d_end, int64_t rows,
+                                          int batch, int64_t length, int64_t index0, int64_t r0,
+                                          int64_t r1, int64_t r2, int dim_z, int dim_y, int dim_x,
+                                          const double *beta, int want_msle, float msle_eps, double *sums,
+                                          void *workspace, size_t workspace_bytes, void *stream)
+{
+    wm_walk::CubeWalk w;
+    wm_walk::CubeStrides cs;
+    wm_walk::CubeDivs dv;
+    const int rc = wm_walk_setup("wm_linear_metrics_walk_f32", vol, files, nvars, Z, Y, X, strides, 1, 1, 1,
+                                 d_mid, d_end, rows, batch, length, index0, r0, r1, r2, dim_z, dim_y,
+                                 dim_x, &w, &cs, &dv);
+    if (rc) return rc;
+    WM_REQUIRE(beta && sums, WM_ERR_INVALID, "wm_linear_metrics_walk_f32: null pointer");
+    if (rows == 0) return WM_OK;
+    WM_REQUIRE(wm_num_cus() > 0, WM_ERR_NO_DEVICE, "wm_linear_metrics_walk_f32: no HIP device");
+    WM_REQUIRE(workspace && workspace_bytes >= wm_linear_metrics_workspace_bytes(), WM_ERR_WORKSPACE,
+               "wm_linear_metrics_walk_f32: workspace of %zu bytes needed, %zu given",
+               wm_linear_metrics_workspace_bytes(), workspace_bytes);
+    hipStream_t st = (hipStream_t)stream;
+    double *partial = (double *)workspace;
+    int grid = 0;                            // every workgroup resident (launch bounds); <= 4 per CU
+    const bool vec = wm_walk::walk_vec_ok(vol, nvars, cs);
+#define LM_WALK_GO(V_, M_)                                                                       \
+    do {                                                                                         \
+    if (vec)                                                                                     \
+        hipLaunchKernelGGL((linear_metrics_walk_kernel<V_, M_, true>), dim3(grid), dim3(BLOCK), 0, st, vol, \
+                           files, Z, Y, X, d_mid, d_end, (long long)rows, w, cs, dv, beta, msle_eps,  \
+                           partial);                                                             \
+    else                                                                                         \
+        hipLaunchKernelGGL((linear_metrics_walk_kernel<V_, M_, false>), dim3(grid), dim3(BLOCK), 0, st, vol, \
+                           files, Z, Y, X, d_mid, d_end, (long long)rows, w, cs, dv, beta, msle_eps,  \
+                           partial);                                                             \
+    } while (0)
+#define LM_WALK(V_)                                                                              \
+    grid = wm_num_cus() * LmWalkCfg<V_>::WPS;                                                    \
+    if (want_msle)                                                                               \
+        LM_WALK_GO(V_, true);                                                                    \
+    else                                                                                         \
+        LM_WALK_GO(V_, false)
+    switch (nvars) {
+    case 1: LM_WALK(1); break;
+    case 2: LM_WALK(2); break;
+    case 3: LM_WALK(3); break;
+    default: LM_WALK(4); break;
+    }
+#undef LM_WALK
+#undef LM_WALK_GO
+    WM_LAUNCH_CHECK("linear_metrics_walk_kernel");
+    hipLaunchKernelGGL(metrics_finish_kernel, dim3(3), dim3(BLOCK), 0, st, (const double *)partial, grid,
+                       (double)rows * (double)nvars, sums);
     WM_LAUNCH_CHECK("metrics_finish_kernel");
     return WM_OK;
 }

@@ -787,6 +787,70 @@ def gather_cubes(vol, cube, d_mid, d_end, rows, origins=None, walk=None, separat
     return (x1, x2, Yo) if separate else (Xo, Yo)
 
 
+def walk_fused_supported(vol, cube):
+    """True when ``gram_walk`` / ``linear_metrics_walk`` take this volume: CUBE_SIZE 1 (the
+    reference's setting, multipleRegression.py:35) and 1..4 variables."""
+    return (isinstance(vol, torch.Tensor) and vol.is_cuda and vol.dtype == torch.float32 and
+            vol.dim() == 5 and 1 <= vol.shape[1] <= 4 and tuple(int(c) for c in cube) == (1, 1, 1)
+            and min(vol.stride()) >= 0)
+
+
+def _walk_args(vol, d_mid, d_end, rows, walk):
+    if not isinstance(vol, torch.Tensor) or not vol.is_cuda or vol.dtype != torch.float32:
+        raise RuntimeError("volume must be a float32 CUDA tensor (there is no CPU fallback)")
+    if vol.dim() != 5:
+        raise ValueError(f"volume must be (files, nvars, Z, Y, X), got {tuple(vol.shape)}")
+    if min(vol.stride()) < 0:
+        raise ValueError("volume views with negative strides are not supported")
+    files, nvars, Z, Y, X = vol.shape
+    r0, r1, r2 = (int(v) for v in walk["region"])
+    dz, dy, dx = (int(v) for v in walk["dims"])
+    strides = (ctypes.c_int64 * 5)(*vol.stride())
+    return nvars, (vol.data_ptr(), files, nvars, Z, Y, X, strides, int(d_mid), int(d_end), int(rows),
+                   int(walk["batch"]), int(walk["length"]), int(walk["index"]), r0, r1, r2, dz, dy, dx)
+
+
+def gram_walk(vol, d_mid, d_end, rows, walk, acc=None):
+    """``gram(*gather_cubes(vol, (1, 1, 1), d_mid, d_end, rows, walk=walk), acc)`` without the rows:
+    the Gram of the region walk's rows [x(t) | x(t + d_end)] ; x(t + d_mid) read straight from the
+    resident volume (``wm_gram_walk_f32``; multipleRegression.py:217-270).  1..4 variables."""
+    nvars, args = _walk_args(vol, d_mid, d_end, rows, walk)
+    D = 3 * nvars + 1
+    if acc is None:
+        acc = torch.zeros((D, D), device=vol.device, dtype=torch.float64)
+    elif acc.shape != (D, D) or acc.dtype != torch.float64 or not acc.is_cuda or \
+            not acc.is_contiguous():
+        raise ValueError(f"acc must be a contiguous CUDA float64 ({D},{D}) tensor")
+    L = _lib.lib()
+    with torch.cuda.device(vol.device):
+        ws = torch.empty((max(L.wm_gram_walk_workspace_bytes(nvars), 8),), device=vol.device,
+                         dtype=torch.uint8)
+        _lib.check(L.wm_gram_walk_f32(*args, acc.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
+    return acc
+
+
+def linear_metrics_walk(vol, d_mid, d_end, rows, walk, beta, sums=None, want_msle=True,
+                        msle_eps=1e-7):
+    """``linear_metrics(*gather_cubes(...), beta, sums)`` without the rows
+    (``wm_linear_metrics_walk_f32``)."""
+    nvars, args = _walk_args(vol, d_mid, d_end, rows, walk)
+    beta = _req(beta, "beta", torch.float64)
+    if tuple(beta.shape) != (2 * nvars + 1, nvars):
+        raise ValueError(f"beta must be ({2 * nvars + 1}, {nvars}), got {tuple(beta.shape)}")
+    if sums is None:
+        sums = torch.zeros((4,), device=vol.device, dtype=torch.float64)
+    elif sums.shape != (4,) or sums.dtype != torch.float64 or not sums.is_cuda:
+        raise ValueError("sums must be a CUDA float64 tensor of 4")
+    L = _lib.lib()
+    with torch.cuda.device(vol.device):
+        ws = torch.empty((max(L.wm_linear_metrics_workspace_bytes(), 8),), device=vol.device,
+                         dtype=torch.uint8)
+        _lib.check(L.wm_linear_metrics_walk_f32(*args, beta.data_ptr(), int(bool(want_msle)),
+                                                float(msle_eps), sums.data_ptr(), ws.data_ptr(),
+                                                ws.numel(), _stream()))
+    return sums
+
+
 def dense_supported(in_features, out_features):
     """Shapes ``wm_dense_*`` take (16-byte rows)."""
     return in_features % 4 == 0 and out_features % 4 == 0
