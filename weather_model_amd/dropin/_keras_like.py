@@ -261,6 +261,11 @@ class LinearStackModel:
         ops.linear_metrics(X, Y, self.beta, sums, want_msle="msle" in self._metric_keys,
                            msle_eps=_MSLE_EPS)
 
+    def _sums_of_walk(self, vol, d_mid, d_end, rows, walk, sums):
+        """``_sums_of`` over rows that are never built (linear_metrics_walk_kernel)."""
+        ops.linear_metrics_walk(vol, d_mid, d_end, rows, walk, self.beta, sums,
+                                want_msle="msle" in self._metric_keys, msle_eps=_MSLE_EPS)
+
     _SUM_SLOT = {"loss": 0, "mean_squared_error": 0, "mae": 1, "msle": 2}
 
     def _finish_sums(self, sums, prefix=""):
@@ -285,13 +290,49 @@ class LinearStackModel:
         n = acc[self.F, self.F]
         return float((sse.clamp_min(0.0) / (n * self.P).clamp_min(1.0)).item())
 
-    def _stream(self, source, steps, chunk_rows, on_chunk, keep_rows_up_to):
+    def _walk_source(self, source):
+        """True when ``source`` can hand its batches over as a walk of the resident volume
+        (``device_walk``) that the fused kernels take for this model's shape."""
+        if os.environ.get("WM_FIT_WALK", "1") == "0" or not hasattr(source, "device_walk"):
+            return False
+        return bool(source.device_walk_ready(self.device, self.F, self.P))
+
+    def _stream(self, source, steps, chunk_rows, on_chunk, keep_rows_up_to, on_walk=None):
         """Feed ``steps`` batches of ``source`` to ``on_chunk(X, Y)`` in device chunks.  Returns a
-        callable that replays the same chunks (for the metrics pass) or None if they are gone."""
-        if self.device.type == "cuda" and hasattr(source, "device_rows") and \
-                getattr(source, "device_ready", lambda: False)():
-            if steps is None:
-                raise ValueError("steps_per_epoch / validation_steps is required for a generator")
+        callable ``replay(fn, walk_fn=None)`` that feeds the same chunks again (for the metrics
+        pass) or None if they are gone.
+        ``on_walk(vol, d_mid, d_end, rows, walk)``: for a generator over a resident volume whose
+        rows the kernels can read themselves (``device_walk``: the reference's CUBE_SIZE 1,
+        multipleRegression.py:35) no rows are built at all -- ``on_walk`` gets the walk instead, and
+        the replay calls ``walk_fn`` the same way."""
+        device_gen = self.device.type == "cuda" and hasattr(source, "device_rows") and \
+            getattr(source, "device_ready", lambda: False)()
+        if device_gen and steps is None:
+            raise ValueError("steps_per_epoch / validation_steps is required for a generator")
+        if device_gen and on_walk is not None and self._walk_source(source):
+            bs = max(1, int(source.rows_per_batch()))
+            per = max(1, (1 << 30) // bs)             # the kernels count rows in 31 bits
+            state = source.get_state()
+
+            def run_walk(fn):
+                left = int(steps)
+                while left > 0:
+                    k = min(per, left)
+                    fn(*source.device_walk(k, self.device))
+                    left -= k
+            run_walk(on_walk)
+            end_state = source.get_state()
+
+            def replay(fn, walk_fn=None):
+                if walk_fn is None:
+                    raise RuntimeError("the rows of this pass were never built: replay needs walk_fn")
+                source.set_state(state)
+                run_walk(walk_fn)
+                source.set_state(end_state)
+            self.rows_from = "volume (wm_gram_walk_f32 / wm_linear_metrics_walk_f32)"
+            return replay
+        if device_gen:
+            self.rows_from = "gathered on the device (wm_gather_cubes_f32)"
             if chunk_rows is None:
                 # rows built on the device: chunks of ~1 GiB, so that the two launches per chunk
                 # (gather, Gram or metrics: ~0.2 ms of GPU time) outlast the host work between them
@@ -322,7 +363,7 @@ class LinearStackModel:
             run(on_chunk, collect=True)
             end_state = source.get_state()
 
-            def replay(fn):
+            def replay(fn, walk_fn=None):
                 if budget["ok"]:
                     for X, Y in kept:
                         fn(X, Y)
@@ -340,7 +381,7 @@ class LinearStackModel:
             return None
         chunks = store.chunks
 
-        def replay(fn):
+        def replay(fn, walk_fn=None):
             for X, Y in chunks:
                 fn(X, Y)
         return replay
@@ -374,7 +415,8 @@ class LinearStackModel:
                 # taken once; a generator yields NEW batches every epoch
                 acc_e.zero_()
                 replay = self._stream(source, steps_per_epoch, chunk_rows,
-                                      lambda X, Y: ops.gram(X, Y, acc_e), max_resident_rows)
+                                      lambda X, Y: ops.gram(X, Y, acc_e), max_resident_rows,
+                                      on_walk=lambda *a: ops.gram_walk(*a, acc=acc_e))
                 dp.reduce_gram_(acc_e)
                 n_epoch = float(acc_e[self.F, self.F].item())     # sum of 1*1 = global row count
                 if n_epoch < 1:
@@ -384,7 +426,8 @@ class LinearStackModel:
                 self.beta, self.ridge = self._solve(total, ridge)
             if replay is not None:
                 sums = self._new_sums()
-                replay(lambda X, Y: self._sums_of(X, Y, sums))
+                replay(lambda X, Y: self._sums_of(X, Y, sums),
+                       lambda *a: self._sums_of_walk(*a, sums))
                 logs = self._finish_sums(sums)
             else:
                 logs = {"loss": self._loss_from_gram(acc_e)}
@@ -394,7 +437,8 @@ class LinearStackModel:
             if validation_data is not None:
                 sums = self._new_sums()
                 self._stream(validation_data, validation_steps, chunk_rows,
-                             lambda X, Y: self._sums_of(X, Y, sums), 0)
+                             lambda X, Y: self._sums_of(X, Y, sums), 0,
+                             on_walk=lambda *a: self._sums_of_walk(*a, sums))
                 logs.update(self._finish_sums(sums, prefix="val_"))
             for k, v in logs.items():
                 hist.history.setdefault(k, []).append(v)
@@ -411,6 +455,7 @@ class LinearStackModel:
                                  "epochs (not an Adam trajectory)",
                        "ridge": self.ridge, "rows": self.rows_seen,
                        "metrics_from": "rows" if replay is not None else "gram (rows not kept)",
+                       "rows_from": getattr(self, "rows_from", "host batches"),
                        "parity": "unpinned: keras/tensorflow absent, no reference fixture; pinned "
                                  "against float64 numpy.linalg.lstsq on the same rows"}
         self.history = hist

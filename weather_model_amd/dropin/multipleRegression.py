@@ -279,6 +279,27 @@ class WeatherDataGenerator:
         self._advance_by(count)
         return X, Y
 
+    def device_walk_ready(self, device, F, P):
+        """May ``device_walk`` stand in for ``device_rows`` for a model of F features and P targets?
+        CUBE_SIZE 1 (:35) with 1..4 tested variables: wm_gram_walk_f32 / wm_linear_metrics_walk_f32."""
+        from weather_model_amd import ops
+        c = CUBE_SIZE[self.iteration]
+        vol = self.device_volume(device)
+        return ops.walk_fused_supported(vol, (c, c, c)) and F == 2 * vol.shape[1] and \
+            P == vol.shape[1] and self.index < (1 << 30)       # the kernels count batches in 31 bits
+
+    def device_walk(self, count, device="cuda"):
+        """The next ``count`` batches as a walk over the resident volume -- the arguments of
+        ``ops.gram_walk`` / ``ops.linear_metrics_walk``: (vol, d_mid, d_end, rows, walk) -- and the
+        generator advanced past them.  The rows are those of ``device_rows(count)``; no row is
+        built."""
+        bs = BATCH_SIZE[self.iteration]
+        vol = self.device_volume(device)
+        walk = {"batch": bs, "length": self.__len__(), "index": self.index,
+                "region": self.region_index, "dims": tuple(self.data_dim[1:4])}
+        self._advance_by(count)
+        return vol, TIME_SPAN // 2, TIME_SPAN, int(count) * bs, walk
+
 
 def create_model(input_shape):
     """start/end inputs -> Flatten -> Concatenate -> Dense(2p, linear) 'layer1' -> Dense(2p,
