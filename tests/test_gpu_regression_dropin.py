@@ -366,6 +366,22 @@ def test_gram_and_metrics_straight_from_the_volume_match_the_gathered_rows():
                     gs = ops.linear_metrics_walk(vol, 3, 6, rows, walk, beta, want_msle=msle)
                     assert gs[3].item() == rows * nv
                     assert torch.allclose(gs, ws, rtol=2e-6, atol=0)
+    # passes over the files longer than a wave's chunk of rows (256 or 512): the kernels then take one
+    # cell per chunk, or two where a chunk crosses into the next pass, instead of decoding every row
+    for nv, bs, index, region in ((1, 16, 0, (0, 0, 0)), (2, 5, 7, (1, 0, 0)), (3, 7, 200, (2, 1, 0)),
+                                  (4, 16, 45, (1, 0, 0)), (1, 3, 1, (0, 0, 0))):
+        files, Z, Y, X = 1400 // nv, 2, 3, 2
+        host = torch.rand((files, nv, Z, Y, X), generator=g)
+        length = (files - 6) // bs
+        walk = {"batch": bs, "length": length, "index": index, "region": region, "dims": (Z, Y, X)}
+        rows = bs * (13 * length + 5) + 3
+        view = host.permute(2, 3, 4, 0, 1).contiguous().cuda().permute(3, 4, 0, 1, 2)
+        Xr, Yr = ops.gather_cubes(view, (1, 1, 1), 3, 6, rows, walk=walk)
+        beta = torch.rand((2 * nv + 1, nv), generator=g, dtype=torch.float64).cuda() / (2 * nv)
+        for vol in (view, host.cuda()):
+            assert torch.allclose(ops.gram_walk(vol, 3, 6, rows, walk), ops.gram(Xr, Yr), rtol=2e-6, atol=0)
+            assert torch.allclose(ops.linear_metrics_walk(vol, 3, 6, rows, walk, beta),
+                                  ops.linear_metrics(Xr, Yr, beta), rtol=2e-6, atol=0)
     # big enough for several trips of the whole grid, point-major
     files, nv, Z, Y, X = 2100, 1, 6, 10, 10
     host = torch.rand((files, nv, Z, Y, X), generator=g)

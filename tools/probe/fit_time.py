@@ -26,9 +26,10 @@ def make(n_files, shape, tested):
 
 nvar = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 262144
-n_files = 120
+n_files = int(sys.argv[3]) if len(sys.argv) > 3 else 120
+grid = tuple(int(v) for v in sys.argv[4].split(",")) if len(sys.argv) > 4 else (12, 100, 100)
 from weather_model_amd.dropin import multipleRegression as mr0
-mr = make(n_files, (1, 12, 100, 100), list(mr0.DATA_VARS)[:nvar])
+mr = make(n_files, (1,) + grid, list(mr0.DATA_VARS)[:nvar])
 stats = [mr.DATA_VARS_MIN, mr.DATA_VARS_MAX, mr.DATA_VARS_MEAN, mr.DATA_VARS_STD]
 all_data = mr.load_data(n_files, 0, stats)
 it = 0
@@ -37,7 +38,8 @@ data_dim = mr.calculate_data_shape(it)
 bs = mr.BATCH_SIZE[it]
 length = int(((n_files * 0.8) // bs) - (mr.TIME_SPAN // bs) - 1)
 start = int(n_files * mr.VALIDATION_SPLIT)
-print("input_shape", input_shape, "batch", bs, "rows/epoch", steps * bs, flush=True)
+print("input_shape", input_shape, "batch", bs, "rows/epoch", steps * bs, "files", n_files, "rows per pass",
+      length * bs, flush=True)
 for chunk in (1 << 18, None, None):
     gen = mr.WeatherDataGenerator(n_files, input_shape, length, data_dim, it, all_data, start, stats)
     assert gen.device_ready()

@@ -72,18 +72,24 @@ __device__ __forceinline__ void decode_small(unsigned ru, const CubeWalk &w, con
 }
 
 // Kernels that read their rows straight from the volume give a wave a CHUNK of consecutive rows
-// (row = chunk start + 64 u + lane).  decode_small costs ~130 vector instructions per row and bound
-// the first version of those kernels (6.8e7 rows of one variable: 0.30 ms where the loads need
+// (row = chunk start + k, k = 64 u + lane).  decode_small costs ~130 vector instructions per row and
+// bound the first version of those kernels (6.8e7 rows of one variable: 0.30 ms where the loads need
 // 0.06); decoding once per 64 rows in the scalar unit still left ~50 scalar instructions per 64 rows
-// on the CU's one scalar ALU (0.20 ms).  The rows of a chunk share their grid cell unless the chunk
-// straddles the start of a pass over the files (the region state moves there, and reaches y and x one
-// and two batches late): the cell then comes from the chunk's FIRST row alone -- wave-uniform
-// arithmetic, once per chunk -- and a row adds its file.  The per-row decode stays for the few chunks
-// at a pass boundary and for the walk's first three batches (raw start state).
+// on the CU's one scalar ALU (0.20 ms).  Per chunk, in wave-uniform (scalar) arithmetic:
+//   * the pass R over the files that batch b0 - 2 belongs to (b0: the chunk's first batch; the region
+//     state reaches y and x one and two batches late, hence the lag), the row `rb` at which pass R + 1
+//     starts, and the z / y / x offsets that the states R and R + 1 select;
+//   * mode 1: the chunk ends before rb -- one cell for all its rows, a row adds its file;
+//   * mode 2: the chunk crosses into pass R + 1 (and not beyond) -- a row picks each of its three
+//     offsets by comparing k with rb, rb + batch, rb + 2 batch;
+//   * mode 0: the walk's first three batches (raw start state) or passes shorter than a chunk --
+//     decode_small per row.
 struct WalkChunk {
-    bool fast;              // one cell for the whole chunk
-    unsigned f0;            // file of the chunk's first row
-    long long cell;         // element offset of the cell (z, y, x part)
+    int mode;
+    int f_cur, f_next;      // file of chunk row k: k + f_cur in pass R, k + f_next in pass R + 1
+    int kb;                 // chunk row at which pass R + 1 starts (mode 2)
+    int bs;
+    long long zc[2], yc[2], xc[2];      // element offsets selected by the states R, R + 1
 };
 
 // base: first row of the chunk (wave-uniform, < rows); count: rows of a chunk
@@ -94,42 +100,57 @@ __device__ __forceinline__ WalkChunk walk_chunk(unsigned base, unsigned count, l
     base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
     const unsigned last = base + count - 1u < (unsigned)rows ? base + count - 1u : (unsigned)rows - 1u;
     const unsigned bs = (unsigned)w.bs, len = (unsigned)w.length;
-    const unsigned b0 = fdiv(base, dv.bs), b1 = fdiv(last, dv.bs);
-    const unsigned ib = (unsigned)w.index0 + b0;
-    const unsigned R0 = fdiv(ib, dv.length);
-    const unsigned pos = ib - R0 * len;                                   // batch within the pass
+    const unsigned b0 = fdiv(base, dv.bs);
     WalkChunk c;
-    // batches pos-2 .. pos+(b1-b0) lie in one pass: R0_b = R0_{b-1} = R0_{b-2} for every row
-    c.fast = b0 >= 3u && pos >= 2u && pos + (b1 - b0) < len;
-    const unsigned r1 = fdiv(R0, dv.dim_z), r2 = fdiv(r1, dv.dim_y);
-    int z0 = (int)(R0 - r1 * (unsigned)w.dim_z);
-    int y0 = (int)(r1 - r2 * (unsigned)w.dim_y);
-    int x0 = (int)(r2 - fdiv(r2, dv.dim_x) * (unsigned)w.dim_x);
-    z0 = max(0, min(z0, Z - 1));
-    y0 = max(0, min(y0, Y - 1));
-    x0 = max(0, min(x0, X - 1));
-    c.f0 = pos * bs + (base - b0 * bs);
-    c.cell = z0 * st.z + y0 * st.y + x0 * st.x;
+    c.mode = 0;
+    c.bs = w.bs;
+    if (b0 >= 3u) {
+        const unsigned R = fdiv((unsigned)w.index0 + b0 - 2u, dv.length);
+        const long long span = (long long)len * bs;                       // rows of a pass
+        const long long rb = ((long long)(R + 1u) * len - w.index0) * bs;
+        c.mode = (long long)last < rb ? 1 : ((long long)last < rb + span ? 2 : 0);
+        c.f_cur = (int)((long long)base - (rb - span));
+        c.f_next = (int)((long long)base - rb);
+        c.kb = (int)(rb - (long long)base);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const unsigned Re = R + (unsigned)e;
+            const unsigned r1 = fdiv(Re, dv.dim_z), r2 = fdiv(r1, dv.dim_y);
+            int z0 = (int)(Re - r1 * (unsigned)w.dim_z);
+            int y0 = (int)(r1 - r2 * (unsigned)w.dim_y);
+            int x0 = (int)(r2 - fdiv(r2, dv.dim_x) * (unsigned)w.dim_x);
+            // the host validated the ranges; clamping keeps a bad walk from faulting the GPU
+            c.zc[e] = max(0, min(z0, Z - 1)) * st.z;
+            c.yc[e] = max(0, min(y0, Y - 1)) * st.y;
+            c.xc[e] = max(0, min(x0, X - 1)) * st.x;
+        }
+    }
     return c;
 }
 
-// Where row r = chunk start + k (k = 64 u + lane) starts in the volume: the value of variable 0 at
-// x(t).  Rows past the end get a clamped, valid address and ok = false.
+// Where row r = chunk start + k starts in the volume: the value of variable 0 at x(t).  Rows past the
+// end get a clamped, valid address and ok = false.
 __device__ __forceinline__ const float *walk_chunk_row(const WalkChunk &c, const float *__restrict__ vol,
                                                        long long r, unsigned k, long long rows, int files,
                                                        int Z, int Y, int X, int dmax, const CubeWalk &w,
                                                        const CubeStrides &st, const CubeDivs &dv, bool &ok)
 {
     ok = r < rows;
-    if (c.fast) {                                                         // wave-uniform branch
-        const unsigned fmax = (unsigned)(files - 1 - dmax);
-        const unsigned f = c.f0 + k < fmax ? c.f0 + k : fmax;
-        return vol + c.cell + (long long)f * st.f;
+    const unsigned fmax = (unsigned)(files - 1 - dmax);
+    if (c.mode == 1) {                                                    // wave-uniform branches
+        const unsigned f = min(k + (unsigned)c.f_cur, fmax);
+        return vol + (c.zc[0] + c.yc[0] + c.xc[0]) + (long long)f * st.f;
+    }
+    if (c.mode == 2) {
+        const int kk = (int)k;
+        const bool i0 = kk >= c.kb, i1 = kk >= c.kb + c.bs, i2 = kk >= c.kb + 2 * c.bs;
+        const unsigned f = min(k + (unsigned)(i0 ? c.f_next : c.f_cur), fmax);
+        const long long cell = (i0 ? c.zc[1] : c.zc[0]) + (i1 ? c.yc[1] : c.yc[0]) + (i2 ? c.xc[1] : c.xc[0]);
+        return vol + cell + (long long)f * st.f;
     }
     long long f;
     int z0, y0, x0;
     decode_small((unsigned)(ok ? r : rows - 1), w, dv, f, z0, y0, x0);
-    // the host validated the ranges; clamping keeps a bad walk from faulting the GPU
     f = max(0ll, min(f, (long long)files - 1 - dmax));
     z0 = max(0, min(z0, Z - 1));
     y0 = max(0, min(y0, Y - 1));
