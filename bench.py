@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the weather-model hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload all|gram16|conv3x3|gram64]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload all|gram16|conv3x3|gram64|fit_walk|...]
 
 One JSON line on stdout (rank 0).  Primary workload (`value`) = BASELINE.json configs[1]:
 16-feature least squares on 1e8 synthetic rows per GPU (Gram build + normal-equation solve),
@@ -413,6 +413,71 @@ def run_gram_family(rank, world, ps=(3, 5, 6, 7, 10, 12), bytes_target=4.8e9):
                                    + ", ".join(str(v) for v in ps)
                                    + ": Gram pass and loss/mae/msle pass on resident rows, HIP events, "
                                      "6 timed launches each"},
+            "shapes": out}
+
+
+def run_fit_walk(rank, world, nvars=(1, 4), files=1200, grid=(16, 64, 64), bs=16):
+    """An epoch of multipleRegression's own fit over a RESIDENT volume (CUBE_SIZE 1, BATCH_SIZE 16,
+    TIME_SPAN 6: multipleRegression.py:29,35,40,217-270), both ways, HIP events around each pass:
+    rows gathered by wm_gather_cubes_f32, then wm_gram_f32 and wm_linear_metrics_f32 -- against
+    wm_gram_walk_f32 and wm_linear_metrics_walk_f32, which read the volume themselves.  The volume is
+    stored point-major (Z, Y, X, files, vars) as the drop-in keeps it; one epoch = one visit of every
+    grid cell (length batches each)."""
+    from weather_model_amd import ops, _lib
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    Z, Y, X = grid
+    out = {}
+    for nv in nvars:
+        stored = torch.empty((Z, Y, X, files, nv), device="cuda", dtype=torch.float32)
+        _lib.check(L.wm_synth_uniform_f32(stored.data_ptr(), stored.numel(), 77 + nv,
+                                          rank * stored.numel(), 0.0, 1.0, st))
+        vol = stored.permute(3, 4, 0, 1, 2)
+        length = (files - 6) // bs - 1
+        walk = {"batch": bs, "length": length, "index": 0, "region": (0, 0, 0), "dims": grid}
+        rows = bs * length * Z * Y * X
+        D = 3 * nv + 1
+        acc = torch.zeros((D, D), device="cuda", dtype=torch.float64)
+        sums = torch.zeros((4,), device="cuda", dtype=torch.float64)
+        ops.gram_walk(vol, 3, 6, rows, walk, acc)
+        beta = ops.normal_solve(acc, 2 * nv, nv)
+        t = {k: [] for k in ("gather", "gram", "metrics", "gram_walk", "metrics_walk")}
+        for i in range(8):
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(8)]
+            ev[0].record()
+            Xr, Yr = ops.gather_cubes(vol, (1, 1, 1), 3, 6, rows, walk=walk)
+            ev[1].record()
+            ops.gram(Xr, Yr, acc)
+            ev[2].record()
+            ops.linear_metrics(Xr, Yr, beta, sums)
+            ev[3].record()
+            del Xr, Yr
+            ev[4].record()
+            ops.gram_walk(vol, 3, 6, rows, walk, acc)
+            ev[5].record()
+            ops.linear_metrics_walk(vol, 3, 6, rows, walk, beta, sums)
+            ev[6].record()
+            torch.cuda.synchronize()
+            if i >= 2:
+                for k, (a, b) in zip(t, ((0, 1), (1, 2), (2, 3), (4, 5), (5, 6))):
+                    t[k].append(ev[a].elapsed_time(ev[b]))
+        ms = {k: float(np.mean(v)) for k, v in t.items()}
+        gb = 4.0 * nv * rows / 1e6                    # every value of the walked files read once
+        rows_ms = ms["gather"] + ms["gram"] + ms["metrics"]
+        walk_ms = ms["gram_walk"] + ms["metrics_walk"]
+        out[f"V{nv}"] = {
+            "rows": rows, "F": 2 * nv, "P": nv, "ms": ms, "epoch_ms_rows": rows_ms, "epoch_ms_walk": walk_ms,
+            "speedup": rows_ms / walk_ms, "rows_per_s_walk": rows / walk_ms * 1e3 * world,
+            "gram_walk_GBs": gb / ms["gram_walk"], "gram_walk_frac": gb / ms["gram_walk"] / HBM_PEAK_GBS,
+            "metrics_walk_GBs": gb / ms["metrics_walk"],
+            "bound": "vector ALU (float32 products per row), not HBM: 4 V bytes per row"}
+        del stored, vol
+        torch.cuda.empty_cache()
+    return {"unit": "ms per pass over one epoch's rows; GB/s of 4 V algorithmic bytes per row",
+            "config": {"workload": f"multipleRegression epoch over a resident volume: {files} files, grid "
+                                   f"{Z}x{Y}x{X}, BATCH_SIZE {bs}, CUBE_SIZE 1, V variables (F = 2V, P = V), "
+                                   f"point-major volume; gather + Gram + metrics against the passes that "
+                                   f"read the volume directly, 6 timed launches each"},
             "shapes": out}
 
 
@@ -1364,7 +1429,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="all", choices=["all", "gram16", "conv3x3", "gram64", "model32", "fields", "conv32", "conv32x3",
                              "conv3d_model", "plumbing", "gram_ref_multi", "gram_ref_single", "gram_mid", "gram_family",
-                             "gram16_normal"])
+                             "gram16_normal", "fit_walk"])
     ap.add_argument("--rows", type=int, default=100_000_000, help="rows per GPU (gram16)")
     ap.add_argument("--rows64", type=int, default=1_250_000_000,
                     help="rows per GPU of the F=64 workload (config 5: 1e10 rows / 8 GPUs)")
@@ -1469,6 +1534,20 @@ def main():
                         "shapes": fam["shapes"]})
         else:
             out.setdefault("also", {})["gram_family"] = fam
+    if args.workload in ("all", "fit_walk"):
+        fw = run_fit_walk(rank, world)
+        if args.workload == "fit_walk":
+            v1 = fw["shapes"]["V1"]
+            out.update({"metric": "regression rows/s (multipleRegression epoch over a resident volume, "
+                                  "Gram + metrics passes reading the volume)",
+                        "value": v1["rows_per_s_walk"], "ms_per_step": v1["epoch_ms_walk"],
+                        "config": fw["config"], "roofline": {
+                            "bound": "hbm", "achieved": v1["gram_walk_GBs"], "peak": HBM_PEAK_GBS,
+                            "unit": "GB/s", "frac": v1["gram_walk_frac"], "traffic": None,
+                            "kernel": "gram_walk_kernel"},
+                        "shapes": fw["shapes"]})
+        else:
+            out.setdefault("also", {})["fit_walk"] = fw
     if args.workload in ("all", "gram64"):
         # config 5: 1e10 rows over 8 GPUs = 1.25e9 rows per GPU; a pass takes ~0.25 s, so the default
         # run keeps the full per-GPU size but caps the step count
