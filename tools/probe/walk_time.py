@@ -19,7 +19,7 @@ def timed(fn, reps=20):
 
 
 def main():
-    for nv in (1, 2, 4):
+    for nv in (1, 2, 3, 4):
         files, Z, Y, X = 4200, 16, 32, 32
         stored = torch.rand((Z, Y, X, files, nv), device="cuda")
         vol = stored.permute(3, 4, 0, 1, 2)

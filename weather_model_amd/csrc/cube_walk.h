@@ -159,13 +159,13 @@ __device__ __forceinline__ const float *walk_chunk_row(const WalkChunk &c, const
 }
 
 // One row's 3 V values: a = x(t), c = x(t + d_end), m = x(t + d_mid).  VEC: the V variables of a point
-// are adjacent and aligned (st.v == 1; the host checks the rest) -- one load per time instead of V.
+// are adjacent (st.v == 1) -- one dword-aligned vector load per time instead of V loads.
 template <int V, bool VEC>
 __device__ __forceinline__ void walk_load(const float *__restrict__ src, const CubeStrides &st, int d_mid,
                                           int d_end, float (&a)[V], float (&c)[V], float (&m)[V])
 {
-    if constexpr (VEC && (V == 2 || V == 4)) {
-        typedef float vec __attribute__((ext_vector_type(V)));
+    if constexpr (VEC && V >= 2) {
+        typedef float vec __attribute__((ext_vector_type(V), aligned(4)));
         const vec va = *reinterpret_cast<const vec *>(src);
         const vec vc = *reinterpret_cast<const vec *>(src + d_end * st.f);
         const vec vm = *reinterpret_cast<const vec *>(src + d_mid * st.f);
@@ -182,11 +182,9 @@ __device__ __forceinline__ void walk_load(const float *__restrict__ src, const C
 }
 
 // host: may walk_load<V, true> be used?
-inline bool walk_vec_ok(const float *vol, int V, const CubeStrides &st)
+inline bool walk_vec_ok(int V, const CubeStrides &st)
 {
-    if (V != 2 && V != 4) return false;
-    return st.v == 1 && st.f % V == 0 && st.z % V == 0 && st.y % V == 0 && st.x % V == 0 &&
-           ((uintptr_t)vol & (uintptr_t)(4 * V - 1)) == 0;
+    return V >= 2 && st.v == 1;
 }
 
 // l = ceil(log2 d); m = floor(2^32 (2^l - d) / d) + 1; q = (t + ((n - t) >> min(l,1))) >> max(l-1,0)

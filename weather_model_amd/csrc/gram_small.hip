@@ -194,7 +194,7 @@ __global__ __launch_bounds__(BLOCK, (SmallCfg<F, P>::WPS)) void gram_small_kerne
 template <int V>
 struct WalkCfg {
     static constexpr int UR = V == 1 ? 8 : 4;
-    static constexpr int WPS = V <= 2 ? 4 : 2;
+    static constexpr int WPS = V <= 2 ? 4 : 2;      // V = 3: 128 VGPRs, V = 4: 220
 };
 
 template <int V, bool VEC>
@@ -395,7 +395,7 @@ extern "C" int wm_gram_walk_f32(const float *vol, int files, int nvars, int Z, i
     hipStream_t st = (hipStream_t)stream;
     double *partial = (double *)workspace;
     int grid = 0;                            // every workgroup resident (launch bounds)
-    const bool vec = wm_walk::walk_vec_ok(vol, nvars, cs);
+    const bool vec = wm_walk::walk_vec_ok(nvars, cs);
 #define WM_WALK(V_)                                                                              \
     grid = wm_num_cus() * WalkCfg<V_>::WPS;                                                      \
     if (vec)                                                                                     \

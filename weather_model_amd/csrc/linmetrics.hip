@@ -1046,7 +1046,7 @@ __global__ __launch_bounds__(BLOCK, 2) void linear_metrics_wide_kernel(
 template <int V>
 struct LmWalkCfg {                         // latency-bound loop: rows per lane and trip, waves per SIMD
     static constexpr int UR = V == 1 ? 8 : 4;
-    static constexpr int WPS = V <= 2 ? 4 : 2;
+    static constexpr int WPS = V <= 3 ? 4 : 2;      // 66-96 VGPRs; V = 4 measured faster at 2
 };
 
 template <int V, bool MSLE, bool VEC>
@@ -1357,7 +1357,7 @@ extern "C" int wm_linear_metrics_walk_f32(const float *vol, int files, int nvars
     hipStream_t st = (hipStream_t)stream;
     double *partial = (double *)workspace;
     int grid = 0;                            // every workgroup resident (launch bounds); <= 4 per CU
-    const bool vec = wm_walk::walk_vec_ok(vol, nvars, cs);
+    const bool vec = wm_walk::walk_vec_ok(nvars, cs);
 #define LM_WALK_GO(V_, M_)                                                                       \
     do {                                                                                         \
     if (vec)                                                                                     \
