@@ -128,7 +128,49 @@ __device__ __forceinline__ WalkChunk walk_chunk(unsigned base, unsigned count, l
     return c;
 }
 
-// Where row r = chunk start + k starts in the volume: the value of variable 0 at x(t).  Rows past the
+// Element offsets at which the chunk's rows r = c0 + k, k = 64 u + lane, start in the volume: the value
+// of variable 0 at x(t).  Rows past the end get a clamped, valid offset.  Offsets, not pointers: a
+// pointer merged from three branches loses its address space and the loads turn into flat loads.  The
+// mode branch sits outside the row loop, so the common mode is straight-line code.
+template <int UR>
+__device__ __forceinline__ void walk_chunk_rows(const WalkChunk &c, long long c0,
+                                                int lane, long long rows, int files, int Z, int Y, int X,
+                                                int dmax, const CubeWalk &w, const CubeStrides &st,
+                                                const CubeDivs &dv, long long (&off)[UR])
+{
+    const unsigned fmax = (unsigned)(files - 1 - dmax);
+    if (c.mode == 1) {                                                    // wave-uniform branches
+        const long long cell = c.zc[0] + c.yc[0] + c.xc[0];
+        const unsigned f0 = (unsigned)c.f_cur + (unsigned)lane;
+#pragma unroll
+        for (int u = 0; u < UR; ++u) off[u] = cell + (long long)min(f0 + 64u * u, fmax) * st.f;
+    } else if (c.mode == 2) {
+#pragma unroll
+        for (int u = 0; u < UR; ++u) {
+            const int kk = u * 64 + lane;
+            const bool i0 = kk >= c.kb, i1 = kk >= c.kb + c.bs, i2 = kk >= c.kb + 2 * c.bs;
+            const unsigned f = min((unsigned)kk + (unsigned)(i0 ? c.f_next : c.f_cur), fmax);
+            const long long cell = (i0 ? c.zc[1] : c.zc[0]) + (i1 ? c.yc[1] : c.yc[0]) + (i2 ? c.xc[1] : c.xc[0]);
+            off[u] = cell + (long long)f * st.f;
+        }
+    } else {
+#pragma unroll 1
+        for (int u = 0; u < UR; ++u) {
+            const long long r = c0 + u * 64 + lane;
+            long long f;
+            int z0, y0, x0;
+            decode_small((unsigned)(r < rows ? r : rows - 1), w, dv, f, z0, y0, x0);
+            f = max(0ll, min(f, (long long)files - 1 - dmax));
+            z0 = max(0, min(z0, Z - 1));
+            y0 = max(0, min(y0, Y - 1));
+            x0 = max(0, min(x0, X - 1));
+            off[u] = f * st.f + z0 * st.z + y0 * st.y + x0 * st.x;
+        }
+    }
+}
+
+// The same for ONE row, as a pointer (gram_walk_kernel<4> schedules better around it: 0.32 against
+// 0.42 ms per 6.8e7 rows).  Where row r = chunk start + k starts in the volume: the value of variable 0 at x(t).  Rows past the
 // end get a clamped, valid address and ok = false.
 __device__ __forceinline__ const float *walk_chunk_row(const WalkChunk &c, const float *__restrict__ vol,
                                                        long long r, unsigned k, long long rows, int files,

@@ -194,7 +194,8 @@ __global__ __launch_bounds__(BLOCK, (SmallCfg<F, P>::WPS)) void gram_small_kerne
 template <int V>
 struct WalkCfg {
     static constexpr int UR = V == 1 ? 8 : 4;
-    static constexpr int WPS = V <= 2 ? 4 : 2;      // V = 3: 128 VGPRs, V = 4: 220
+    static constexpr int WPS = V <= 2 ? 4 : 2;      // V = 3: 128 VGPRs, V = 4: 220 (6 per SIMD at V = 1: slower)
+    static constexpr bool BY_ROW = V == 4;          // address per row inside the load loop (measured)
 };
 
 template <int V, bool VEC>
@@ -221,13 +222,20 @@ __global__ __launch_bounds__(BLOCK, WalkCfg<V>::WPS) void gram_walk_kernel(
         const long long c0 = ch * CHUNK;
         const wm_walk::WalkChunk wc = wm_walk::walk_chunk((unsigned)c0, CHUNK, rows, Z, Y, X, w, st, dv);
         float z[UR][C::M];
+        long long off[UR];
+        if constexpr (!WalkCfg<V>::BY_ROW)
+            wm_walk::walk_chunk_rows<UR>(wc, c0, lane, rows, files, Z, Y, X, dmax, w, st, dv, off);
 #pragma unroll
         for (int u = 0; u < UR; ++u) {
-            bool ok;
-            const float *src = wm_walk::walk_chunk_row(wc, vol, c0 + u * 64 + lane, (unsigned)(u * 64 + lane),
-                                                       rows, files, Z, Y, X, dmax, w, st, dv, ok);
             float a[V], c[V], m[V];
-            wm_walk::walk_load<V, VEC>(src, st, d_mid, d_end, a, c, m);
+            bool ok = c0 + u * 64 + lane < rows;
+            if constexpr (WalkCfg<V>::BY_ROW) {
+                const float *src = wm_walk::walk_chunk_row(wc, vol, c0 + u * 64 + lane, (unsigned)(u * 64 + lane),
+                                                           rows, files, Z, Y, X, dmax, w, st, dv, ok);
+                wm_walk::walk_load<V, VEC>(src, st, d_mid, d_end, a, c, m);
+            } else {
+                wm_walk::walk_load<V, VEC>(vol + off[u], st, d_mid, d_end, a, c, m);
+            }
 #pragma unroll
             for (int v = 0; v < V; ++v) {
                 z[u][v] = ok ? a[v] : 0.f;
@@ -370,7 +378,7 @@ extern "C" size_t wm_gram_walk_workspace_bytes(int nvars)
 {
     if (nvars < 1 || nvars > 4 || wm_num_cus() <= 0) return 0;
     const int M = 3 * nvars;
-    return (size_t)wm_num_cus() * 4 * (M * (M + 1) / 2 + M) * sizeof(double);     // WalkCfg::WPS <= 4
+    return (size_t)wm_num_cus() * 8 * (M * (M + 1) / 2 + M) * sizeof(double);     // WalkCfg::WPS <= 8
 }
 
 extern "C" int wm_gram_walk_f32(const float *vol, int files, int nvars, int Z, int Y, int X,

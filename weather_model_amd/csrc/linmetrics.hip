@@ -1067,12 +1067,13 @@ __global__ __launch_bounds__(BLOCK, LmWalkCfg<V>::WPS) void linear_metrics_walk_
         const wm_walk::WalkChunk wc = wm_walk::walk_chunk((unsigned)c0, CHUNK, rows, Z, Y, X, w, st, dv);
         float x[LM_WALK_UR][F], y[LM_WALK_UR * P], pred[LM_WALK_UR * P];
         bool ok[LM_WALK_UR];
+        long long off[LM_WALK_UR];
+        wm_walk::walk_chunk_rows<LM_WALK_UR>(wc, c0, lane, rows, files, Z, Y, X, dmax, w, st, dv, off);
 #pragma unroll
         for (int u = 0; u < LM_WALK_UR; ++u) {
-            const float *src = wm_walk::walk_chunk_row(wc, vol, c0 + u * 64 + lane, (unsigned)(u * 64 + lane),
-                                                       rows, files, Z, Y, X, dmax, w, st, dv, ok[u]);
             float a[V], c[V], m[V];
-            wm_walk::walk_load<V, VEC>(src, st, d_mid, d_end, a, c, m);
+            wm_walk::walk_load<V, VEC>(vol + off[u], st, d_mid, d_end, a, c, m);
+            ok[u] = c0 + u * 64 + lane < rows;
 #pragma unroll
             for (int v = 0; v < V; ++v) {
                 x[u][v] = a[v];
