@@ -363,7 +363,7 @@ int wm_walk_setup(const char *who, const float *vol, int files, int nvars, int Z
     const long long lim = 1ll << 31;
     const long long last_b = index0 + rows / batch + 2;
     WM_REQUIRE(rows < lim && last_b < lim && length < lim && r0 < lim && r1 < lim && r2 < lim &&
-                   (length + 1) * batch < lim,
+                   (length + 1) * batch < lim && batch <= (1 << 24),
                WM_ERR_UNSUPPORTED, "%s: walk counts beyond 2^31 (gather in pieces instead)", who);
     *w = {length, index0, r0, r1, r2, batch, dim_z, dim_y, dim_x};
     *cs = {strides[0], strides[1], strides[2], strides[3], strides[4]};
