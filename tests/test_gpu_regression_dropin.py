@@ -405,6 +405,57 @@ def test_gram_and_metrics_straight_from_the_volume_match_the_gathered_rows():
     assert ops.gram_walk(view, 3, 6, 0, walk).abs().sum().item() == 0
 
 
+def test_gather_cubes_wave_per_row_kernel_matches_numpy_slicing():
+    """Rows of 64..256 elements take gather_cubes_rows_kernel (a wave per row, singleRegression's 6^3
+    cubes: p = 216): bit for bit numpy slicing along the reference's region walk (tuple update of
+    singleRegression.py:330-340 restated below) and for explicit origins, at both ends of the size
+    range, with several variables, on a row-major volume and a strided view, with a row count that
+    leaves the last trip half empty."""
+    from weather_model_amd import ops
+    g = torch.Generator().manual_seed(9)
+    for nv, cube, bs in ((1, (6, 6, 6), 4), (1, (4, 4, 4), 3), (3, (2, 4, 4), 5), (1, (4, 8, 8), 4),
+                         (2, (5, 5, 5), 16)):
+        files, Z, Y, X = 40, 8, 9, 10
+        host = torch.rand((files, nv, Z, Y, X), generator=g)
+        hn = host.numpy()
+        p = nv * cube[0] * cube[1] * cube[2]
+        assert 64 <= p <= 256
+        length = (files - 2) // bs - 1
+        dims = (Z - cube[0] + 1, Y - cube[1] + 1, X - cube[2] + 1)
+        index, region = 2, (1, 0, 0)
+        walk = {"batch": bs, "length": length, "index": index, "region": region, "dims": dims}
+        rows = bs * (3 * length + 2) + 1
+        want_x1 = np.empty((rows, p), np.float32)
+        want_x2 = np.empty((rows, p), np.float32)
+        want_y = np.empty((rows, p), np.float32)
+        for r in range(rows):
+            if r % bs == 0 and r > 0:
+                index += 1
+                region = (index // length, region[0] // dims[0], region[1] // dims[1])
+            f = (index % length) * bs + r % bs
+            z0, y0, x0 = region[0] % dims[0], region[1] % dims[1], region[2] % dims[2]
+            cut = lambda ff: hn[ff, :, z0:z0 + cube[0], y0:y0 + cube[1], x0:x0 + cube[2]].reshape(-1)  # noqa: E731
+            want_x1[r], want_x2[r], want_y[r] = cut(f), cut(f + 2), cut(f + 1)
+        stored = host.permute(2, 3, 4, 0, 1).contiguous().cuda()
+        for vol in (host.cuda(), stored.permute(3, 4, 0, 1, 2)):
+            x1, x2, y = ops.gather_cubes(vol, cube, 1, 2, rows, walk=walk, separate=True)
+            assert np.array_equal(x1.cpu().numpy(), want_x1)
+            assert np.array_equal(x2.cpu().numpy(), want_x2)
+            assert np.array_equal(y.cpu().numpy(), want_y)
+            Xc, Yc = ops.gather_cubes(vol, cube, 1, 2, rows, walk=walk)
+            assert np.array_equal(Xc.cpu().numpy(), np.concatenate([want_x1, want_x2], axis=1))
+            assert np.array_equal(Yc.cpu().numpy(), want_y)
+        rng = np.random.default_rng(nv + bs)
+        org = np.stack([rng.integers(0, files - 2, 37), rng.integers(0, dims[0], 37),
+                        rng.integers(0, dims[1], 37), rng.integers(0, dims[2], 37)], axis=1).astype(np.int32)
+        x1, x2, y = ops.gather_cubes(host.cuda(), cube, 1, 2, 37, origins=org, separate=True)
+        for r, (f, z0, y0, x0) in enumerate(org):
+            cut = lambda ff: hn[ff, :, z0:z0 + cube[0], y0:y0 + cube[1], x0:x0 + cube[2]].reshape(-1)  # noqa: E731
+            assert np.array_equal(x1[r].cpu().numpy(), cut(f))
+            assert np.array_equal(x2[r].cpu().numpy(), cut(f + 2))
+            assert np.array_equal(y[r].cpu().numpy(), cut(f + 1))
+
+
 def test_fit_without_resident_rows_reports_gram_loss():
     """Rows beyond max_resident_rows are not kept: the loss then comes from the Gram itself
     (MSE = (Y'Y - 2 b'Z'Y + b'Z'Zb) / nP) and agrees with the row-based loss."""

@@ -352,6 +352,96 @@ __global__ __launch_bounds__(BLOCK) void gather_cubes_kernel(
     }
 }
 
+// Rows of 64 ... 256 elements (singleRegression's 6^3 cubes of one variable: p = 216).  The kernel
+// above decodes (row, element) -> (file, origin, variable, dz, dy, dx) for EVERY element: ~170 vector
+// instructions for three loads and three stores, and it ran singleRegression's rows at 2.1 ms per 1e6
+// (2.4 TB/s of useful bytes; the Gram pass they feed takes 4.7 ms).  Here a wave owns a row: the row's
+// (file, origin) is wave-uniform -- scalar arithmetic, or scalar loads of `origins` -- and the offset
+// of element q inside a cube does not depend on the row at all, so every lane decodes its NQ elements
+// (q = 64 j + lane) once, before the row loop.  Per element that leaves an add, three loads and three
+// stores; the stores of a row are contiguous.  Four rows per trip keep 12 NQ loads in flight.
+constexpr int GATHER_ROWS_UR = 4;
+
+template <int NQ>
+__global__ __launch_bounds__(BLOCK) void gather_cubes_rows_kernel(
+    const float *__restrict__ vol, int files, int nvars, int Z, int Y, int X, int cz, int cy,
+    int cx, int d_mid, int d_end, const int *__restrict__ origins, long long rows, CubeWalk w,
+    CubeStrides st, CubeDivs dv, float *__restrict__ x1out, float *__restrict__ x2out,
+    long long xstride, float *__restrict__ yout)
+{
+    constexpr int UR = GATHER_ROWS_UR;
+    const int p = nvars * cz * cy * cx;
+    const int dmax = d_mid > d_end ? d_mid : d_end;
+    const int lane = threadIdx.x & 63;
+    const long long nwaves = (long long)gridDim.x * (BLOCK / 64);
+    const long long wave_id = (long long)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    long long off[NQ];
+    bool live[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        const int q = j * 64 + lane;
+        live[j] = q < p;
+        unsigned t = (unsigned)(live[j] ? q : 0), u = fdiv(t, dv.cx);
+        const int ix = (int)(t - u * (unsigned)cx); t = u; u = fdiv(t, dv.cy);
+        const int iy = (int)(t - u * (unsigned)cy); t = u; u = fdiv(t, dv.cz);
+        const int iz = (int)(t - u * (unsigned)cz);
+        off[j] = (long long)u * st.v + iz * st.z + iy * st.y + ix * st.x;
+    }
+    for (long long r0 = wave_id * UR; r0 < rows; r0 += nwaves * UR) {
+        long long base[UR];
+        bool ok[UR];
+#pragma unroll
+        for (int k = 0; k < UR; ++k) {
+            const unsigned ru = (unsigned)__builtin_amdgcn_readfirstlane((int)(r0 + k < rows ? r0 + k : rows - 1));
+            ok[k] = r0 + k < rows;
+            long long f;
+            int z0, y0, x0;
+            if (origins) {
+                f = origins[4 * (long long)ru];
+                z0 = origins[4 * (long long)ru + 1];
+                y0 = origins[4 * (long long)ru + 2];
+                x0 = origins[4 * (long long)ru + 3];
+            } else {
+                decode_small(ru, w, dv, f, z0, y0, x0);
+            }
+            // the host validated the ranges; clamping keeps a bad origin from faulting the GPU
+            f = max(0ll, min(f, (long long)files - 1 - dmax));
+            z0 = max(0, min(z0, Z - cz));
+            y0 = max(0, min(y0, Y - cy));
+            x0 = max(0, min(x0, X - cx));
+            base[k] = f * st.f + z0 * st.z + y0 * st.y + x0 * st.x;
+        }
+        float a[UR][NQ], c[UR][NQ], m[UR][NQ];
+#pragma unroll
+        for (int k = 0; k < UR; ++k)
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                const float *src = vol + base[k] + off[j];
+                a[k][j] = src[0];
+                c[k][j] = src[d_end * st.f];
+                m[k][j] = src[d_mid * st.f];
+            }
+#pragma unroll
+        for (int k = 0; k < UR; ++k) {
+            const long long r = r0 + k;
+#pragma unroll
+            for (int j = 0; j < NQ; ++j)
+                if (ok[k] && live[j]) {
+                    const int q = j * 64 + lane;
+                    __builtin_nontemporal_store(a[k][j], x1out + r * xstride + q);
+                    __builtin_nontemporal_store(c[k][j], x2out + r * xstride + q);
+                    __builtin_nontemporal_store(m[k][j], yout + r * (long long)p + q);
+                }
+        }
+    }
+}
+
+bool gather_rows_off()                     // probe switch: WM_GATHER_ROWS=0 keeps the per-element kernel
+{
+    static const bool v = [] { const char *e = getenv("WM_GATHER_ROWS"); return e && e[0] == '0'; }();
+    return v;
+}
+
 int stream_grid(long long work_items, int per_cu = 8)
 {
     long long g = (work_items + BLOCK - 1) / BLOCK;
@@ -532,6 +622,16 @@ extern "C" int wm_gather_cubes_strided_f32(const float *vol, int files, int nvar
                          fast_div((unsigned)(origins ? 1 : dim_y)),
                          fast_div((unsigned)(origins ? 1 : dim_x)), fast_div((unsigned)cx),
                          fast_div((unsigned)cy), fast_div((unsigned)cz)};
+    if (small && !vec4 && p >= 64 && p <= 256 && !gather_rows_off()) {
+        // a wave per row, GATHER_ROWS_UR rows per trip; every workgroup resident or the rows run out first
+        const long long want = (rows + GATHER_ROWS_UR * (BLOCK / 64) - 1) / (GATHER_ROWS_UR * (BLOCK / 64));
+        const long long cap = (long long)wm_num_cus() * 8;
+        hipLaunchKernelGGL(gather_cubes_rows_kernel<4>, dim3((unsigned)(want < cap ? want : cap)), dim3(BLOCK),
+                           0, (hipStream_t)stream, vol, files, nvars, Z, Y, X, cz, cy, cx, d_mid, d_end,
+                           origins, (long long)rows, w, cs, dv, x1out, x2out, (long long)xstride, yout);
+        WM_LAUNCH_CHECK("gather_cubes_rows_kernel");
+        return WM_OK;
+    }
     auto kern = vec4 ? gather_cubes_kernel<true, 4>
                      : (small ? gather_cubes_kernel<true, 1> : gather_cubes_kernel<false, 1>);
     hipLaunchKernelGGL(kern, dim3(stream_grid(units, 4)), dim3(BLOCK), 0, (hipStream_t)stream, vol,
