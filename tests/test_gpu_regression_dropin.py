@@ -403,6 +403,22 @@ def test_gram_and_metrics_straight_from_the_volume_match_the_gathered_rows():
         ops.gram_walk(view[:60], 3, 6, 16,
                       {"batch": 16, "length": 4, "index": 0, "region": (0, 0, 0), "dims": (2, 2, 2)})
     assert ops.gram_walk(view, 3, 6, 0, walk).abs().sum().item() == 0
+    # straight through the C ABI: a workspace that is too small is refused, nothing is launched
+    import ctypes
+    L = _lib.lib()
+    acc = torch.zeros((4, 4), device="cuda", dtype=torch.float64)
+    small_ws = torch.empty((64,), device="cuda", dtype=torch.uint8)
+    strides = (ctypes.c_int64 * 5)(*view.stride())
+    args = (view.data_ptr(), files, 1, Z, Y, X, strides, 3, 6, 1024, 64, walk["length"], 0, 0, 0, 0, Z, Y, X)
+    assert L.wm_gram_walk_workspace_bytes(1) > 64 and L.wm_gram_walk_workspace_bytes(5) == 0
+    rc = L.wm_gram_walk_f32(*args, acc.data_ptr(), small_ws.data_ptr(), small_ws.numel(), 0)
+    assert rc < 0 and acc.abs().sum().item() == 0
+    sums = torch.zeros((4,), device="cuda", dtype=torch.float64)
+    rc = L.wm_linear_metrics_walk_f32(*args, beta.data_ptr(), 1, 1e-7, sums.data_ptr(), small_ws.data_ptr(),
+                                      small_ws.numel(), 0)
+    assert rc < 0 and sums.abs().sum().item() == 0
+    with pytest.raises(_lib.WmError, match="leaves the grid"):
+        ops.gram_walk(view, 3, 6, 16, dict(walk, dims=(Z + 1, Y, X)))
 
 
 def test_gather_cubes_wave_per_row_kernel_matches_numpy_slicing():
