@@ -56,6 +56,21 @@ def test_version_and_error_text_without_gpu():
     assert b"null pointer" in L.wm_last_error()
     rc = L.wm_gram_f32(0, 0, 10, 16, 1, 0, 0, 0, 0)
     assert rc == -1
+    # the volume-reading fit passes: the walk is validated on the host before anything is launched
+    buf = ctypes.create_string_buffer(64)
+    vol = ctypes.cast(buf, ctypes.c_void_p)
+    strides = (ctypes.c_int64 * 5)(1, 1, 1, 1, 1)
+    walk = (3, 6, 16, 16, 4, 0, 0, 0, 0, 2, 2, 2)         # d_mid, d_end, rows, batch, length, index0, r0-2, dims
+    assert L.wm_gram_walk_f32(vol, 80, 5, 2, 2, 2, strides, *walk, vol, vol, 64, 0) < 0
+    assert b"1..4 variables" in L.wm_last_error()
+    assert L.wm_gram_walk_f32(vol, 60, 1, 2, 2, 2, strides, *walk, vol, vol, 64, 0) < 0
+    assert b"resident files" in L.wm_last_error()
+    assert L.wm_linear_metrics_walk_f32(vol, 80, 1, 2, 2, 2, None, *walk, vol, 1, 1e-7, vol, vol, 64, 0) < 0
+    assert b"null pointer" in L.wm_last_error()
+    bad = (3, 6, 16, 16, 4, 0, 0, 0, 0, 3, 2, 2)          # walk region beyond the grid
+    assert L.wm_linear_metrics_walk_f32(vol, 80, 1, 2, 2, 2, strides, *bad, vol, 1, 1e-7, vol, vol, 64, 0) < 0
+    assert b"leaves the grid" in L.wm_last_error()
+    assert L.wm_gram_walk_workspace_bytes(7) == 0
 
 
 def test_ops_refuse_cpu_tensors():
