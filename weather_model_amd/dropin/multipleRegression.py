@@ -258,8 +258,10 @@ class WeatherDataGenerator:
                 # cube 1: a row takes ONE value per (file, variable) plane.  Stored point-major,
                 # (Z, Y, X, files, vars), the rows of a batch (consecutive files at one grid point)
                 # are one contiguous read; the kernel sees the same logical axes through strides
-                stored = torch.from_numpy(np.ascontiguousarray(host.transpose(2, 3, 4, 0, 1)))
-                vol = stored.to(want).permute(3, 4, 0, 1, 2)
+                # (the transposition runs on the device: numpy's strided copy of the same array
+                # takes seconds per GB on the host)
+                stored = torch.from_numpy(host).to(want).permute(2, 3, 4, 0, 1).contiguous()
+                vol = stored.permute(3, 4, 0, 1, 2)
             else:
                 vol = torch.from_numpy(np.ascontiguousarray(host)).to(want)
             self._vol = vol
