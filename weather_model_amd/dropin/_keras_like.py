@@ -409,6 +409,7 @@ class LinearStackModel:
             c.reset()
         replay = None
         self.rows_seen = 0
+        self.rows_from = "host batches"          # _stream overwrites it for a device generator
         for epoch in range(epochs):
             if not (fixed_rows and epoch > 0):
                 # the same arrays every epoch add nothing to a least-squares fit: their Gram is
