@@ -472,6 +472,47 @@ def test_gather_cubes_wave_per_row_kernel_matches_numpy_slicing():
             assert np.array_equal(y[r].cpu().numpy(), cut(f + 1))
 
 
+def test_gather_cubes_cube1_long_passes_match_the_reference_update_rule():
+    """CUBE_SIZE 1 with passes over the files that are long against a wave's 64 units: the gather (and
+    the volume-reading Gram / metrics kernels, which share cube_walk.h's chunk decode) against a
+    literal host restatement of the reference's update rule (multipleRegression.py:259-270: every
+    entry of the region index lags the one before it by a step), row by row, bit for bit -- scalar
+    and four-variables-per-thread paths, row-major and point-major volumes, walks that start
+    mid-state, several passes so that all three coordinates move."""
+    from weather_model_amd import ops
+    g = torch.Generator().manual_seed(21)
+    for nv, bs, index, region in ((1, 16, 0, (0, 0, 0)), (4, 5, 7, (1, 0, 0)), (8, 16, 3, (2, 1, 0)),
+                                  (3, 7, 130, (1, 1, 0)), (5, 4, 0, (0, 0, 0))):
+        files, Z, Y, X = 500, 2, 2, 3
+        host = torch.rand((files, nv, Z, Y, X), generator=g)
+        hn = host.numpy()
+        length = (files - 6) // bs
+        dims = (Z, Y, X)
+        walk = {"batch": bs, "length": length, "index": index, "region": region, "dims": dims}
+        rows = bs * (7 * length + 3) + 2
+        want_x = np.empty((rows, 2 * nv), np.float32)
+        want_y = np.empty((rows, nv), np.float32)
+        i, reg = index, region
+        for r in range(rows):
+            if r % bs == 0 and r > 0:
+                i += 1
+                reg = (i // length, reg[0] // dims[0], reg[1] // dims[1])
+            f = (i % length) * bs + r % bs
+            z0, y0, x0 = reg[0] % dims[0], reg[1] % dims[1], reg[2] % dims[2]
+            want_x[r, :nv] = hn[f, :, z0, y0, x0]
+            want_x[r, nv:] = hn[f + 6, :, z0, y0, x0]
+            want_y[r] = hn[f + 3, :, z0, y0, x0]
+        stored = host.permute(2, 3, 4, 0, 1).contiguous().cuda()
+        for vol in (host.cuda(), stored.permute(3, 4, 0, 1, 2)):
+            Xr, Yr = ops.gather_cubes(vol, (1, 1, 1), 3, 6, rows, walk=walk)
+            assert np.array_equal(Xr.cpu().numpy(), want_x)
+            assert np.array_equal(Yr.cpu().numpy(), want_y)
+        if nv <= 4:
+            Zh = np.concatenate([want_x, np.ones((rows, 1), np.float32), want_y], axis=1).astype(np.float64)
+            got = ops.gram_walk(stored.permute(3, 4, 0, 1, 2), 3, 6, rows, walk).cpu().numpy()
+            np.testing.assert_allclose(got, Zh.T @ Zh, rtol=2e-6)
+
+
 def test_fit_without_resident_rows_reports_gram_loss():
     """Rows beyond max_resident_rows are not kept: the loss then comes from the Gram itself
     (MSE = (Y'Y - 2 b'Z'Y + b'Z'Zb) / nP) and agrees with the row-based loss."""
