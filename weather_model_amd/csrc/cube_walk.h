@@ -223,45 +223,6 @@ __device__ __forceinline__ void walk_load(const float *__restrict__ src, const C
     }
 }
 
-// The common case made cheap: a point-major volume (st.v == 1, st.f == V: the files of a cell are one
-// contiguous run of V-vectors), a chunk in mode 1 that is whole (no row past the end) and stays below
-// the file clamp.  Row k's values then sit at pa[k V + v] from a wave-uniform base: the loads take a
-// scalar base, ONE lane offset and an immediate per row -- no address arithmetic per row and no
-// validity selects (31 -> ~12 vector instructions per row at V = 1).
-template <int V, int UR>
-__device__ __forceinline__ bool walk_chunk_dense(const WalkChunk &c, const CubeStrides &st, long long c0,
-                                                 long long rows, int files, int dmax)
-{
-    return c.mode == 1 && st.v == 1 && st.f == V && c0 + 64 * UR <= rows &&
-           (long long)c.f_cur + 64 * UR - 1 <= (long long)files - 1 - dmax;
-}
-
-template <int V, int UR>
-__device__ __forceinline__ void walk_load_dense(const WalkChunk &c, const float *__restrict__ vol, int lane,
-                                                int d_mid, int d_end, float (&a)[UR][V], float (&cc)[UR][V],
-                                                float (&m)[UR][V])
-{
-    const float *pa = vol + (c.zc[0] + c.yc[0] + c.xc[0]) + (long long)c.f_cur * V;      // wave-uniform
-    const float *pc = pa + (long long)d_end * V;
-    const float *pm = pa + (long long)d_mid * V;
-    const unsigned l = (unsigned)lane * V;
-#pragma unroll
-    for (int u = 0; u < UR; ++u) {
-        if constexpr (V == 1) {
-            a[u][0] = pa[l + u * 64];
-            cc[u][0] = pc[l + u * 64];
-            m[u][0] = pm[l + u * 64];
-        } else {
-            typedef float vec __attribute__((ext_vector_type(V), aligned(4)));
-            const vec va = *reinterpret_cast<const vec *>(pa + (l + u * 64 * V));
-            const vec vc = *reinterpret_cast<const vec *>(pc + (l + u * 64 * V));
-            const vec vm = *reinterpret_cast<const vec *>(pm + (l + u * 64 * V));
-#pragma unroll
-            for (int v = 0; v < V; ++v) { a[u][v] = va[v]; cc[u][v] = vc[v]; m[u][v] = vm[v]; }
-        }
-    }
-}
-
 // host: may walk_load<V, true> be used?
 inline bool walk_vec_ok(int V, const CubeStrides &st)
 {

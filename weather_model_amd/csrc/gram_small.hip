@@ -194,7 +194,7 @@ __global__ __launch_bounds__(BLOCK, (SmallCfg<F, P>::WPS)) void gram_small_kerne
 template <int V>
 struct WalkCfg {
     static constexpr int UR = V == 1 ? 8 : 4;
-    static constexpr int WPS = V <= 2 ? 4 : 2;      // 78 / 81 / 146 / 221 VGPRs (6 per SIMD at V = 1: no gain)
+    static constexpr int WPS = V <= 2 ? 4 : 2;      // V = 3: 128 VGPRs, V = 4: 220 (6 per SIMD at V = 1: slower)
     static constexpr bool BY_ROW = V == 4;          // address per row inside the load loop (measured)
 };
 
@@ -221,41 +221,28 @@ __global__ __launch_bounds__(BLOCK, WalkCfg<V>::WPS) void gram_walk_kernel(
     for (long long ch = wave_id; ch < nchunks; ch += nwaves) {
         const long long c0 = ch * CHUNK;
         const wm_walk::WalkChunk wc = wm_walk::walk_chunk((unsigned)c0, CHUNK, rows, Z, Y, X, w, st, dv);
-        float a[UR][V], c[UR][V], m[UR][V];
-        if (wm_walk::walk_chunk_dense<V, UR>(wc, st, c0, rows, files, dmax)) {        // wave-uniform
-            wm_walk::walk_load_dense<V, UR>(wc, vol, lane, d_mid, d_end, a, c, m);
-        } else {
-            long long off[UR];
-            if constexpr (!WalkCfg<V>::BY_ROW)
-                wm_walk::walk_chunk_rows<UR>(wc, c0, lane, rows, files, Z, Y, X, dmax, w, st, dv, off);
-#pragma unroll
-            for (int u = 0; u < UR; ++u) {
-                bool ok = c0 + u * 64 + lane < rows;
-                if constexpr (WalkCfg<V>::BY_ROW) {
-                    const float *src = wm_walk::walk_chunk_row(wc, vol, c0 + u * 64 + lane,
-                                                               (unsigned)(u * 64 + lane), rows, files, Z, Y, X,
-                                                               dmax, w, st, dv, ok);
-                    wm_walk::walk_load<V, VEC>(src, st, d_mid, d_end, a[u], c[u], m[u]);
-                } else {
-                    wm_walk::walk_load<V, VEC>(vol + off[u], st, d_mid, d_end, a[u], c[u], m[u]);
-                }
-#pragma unroll
-                for (int v = 0; v < V; ++v) {
-                    a[u][v] = ok ? a[u][v] : 0.f;
-                    c[u][v] = ok ? c[u][v] : 0.f;
-                    m[u][v] = ok ? m[u][v] : 0.f;
-                }
-            }
-        }
         float z[UR][C::M];
+        long long off[UR];
+        if constexpr (!WalkCfg<V>::BY_ROW)
+            wm_walk::walk_chunk_rows<UR>(wc, c0, lane, rows, files, Z, Y, X, dmax, w, st, dv, off);
 #pragma unroll
-        for (int u = 0; u < UR; ++u)
+        for (int u = 0; u < UR; ++u) {
+            float a[V], c[V], m[V];
+            bool ok = c0 + u * 64 + lane < rows;
+            if constexpr (WalkCfg<V>::BY_ROW) {
+                const float *src = wm_walk::walk_chunk_row(wc, vol, c0 + u * 64 + lane, (unsigned)(u * 64 + lane),
+                                                           rows, files, Z, Y, X, dmax, w, st, dv, ok);
+                wm_walk::walk_load<V, VEC>(src, st, d_mid, d_end, a, c, m);
+            } else {
+                wm_walk::walk_load<V, VEC>(vol + off[u], st, d_mid, d_end, a, c, m);
+            }
 #pragma unroll
             for (int v = 0; v < V; ++v) {
-                z[u][v] = a[u][v];
-                z[u][V + v] = c[u][v];
-                z[u][2 * V + v] = m[u][v];
+                z[u][v] = ok ? a[v] : 0.f;
+                z[u][V + v] = ok ? c[v] : 0.f;
+                z[u][2 * V + v] = ok ? m[v] : 0.f;
             }
+        }
 #pragma unroll
         for (int u = 0; u < UR; ++u) small_row<F, P>(acc, z[u]);
         since += UR;

@@ -1065,65 +1065,30 @@ __global__ __launch_bounds__(BLOCK, LmWalkCfg<V>::WPS) void linear_metrics_walk_
     for (long long ch = wave_id; ch < nchunks; ch += nwaves) {
         const long long c0 = ch * CHUNK;
         const wm_walk::WalkChunk wc = wm_walk::walk_chunk((unsigned)c0, CHUNK, rows, Z, Y, X, w, st, dv);
-        float y[LM_WALK_UR * P], pred[LM_WALK_UR * P];
+        float x[LM_WALK_UR][F], y[LM_WALK_UR * P], pred[LM_WALK_UR * P];
         bool ok[LM_WALK_UR];
-        if constexpr (V <= 3) {
-            float a[LM_WALK_UR][V], c[LM_WALK_UR][V], m[LM_WALK_UR][V];
-            if (wm_walk::walk_chunk_dense<V, LM_WALK_UR>(wc, st, c0, rows, files, dmax)) {     // wave-uniform
-                wm_walk::walk_load_dense<V, LM_WALK_UR>(wc, vol, lane, d_mid, d_end, a, c, m);
+        long long off[LM_WALK_UR];
+        wm_walk::walk_chunk_rows<LM_WALK_UR>(wc, c0, lane, rows, files, Z, Y, X, dmax, w, st, dv, off);
 #pragma unroll
-                for (int u = 0; u < LM_WALK_UR; ++u) ok[u] = true;
-            } else {
-                long long off[LM_WALK_UR];
-                wm_walk::walk_chunk_rows<LM_WALK_UR>(wc, c0, lane, rows, files, Z, Y, X, dmax, w, st, dv, off);
+        for (int u = 0; u < LM_WALK_UR; ++u) {
+            float a[V], c[V], m[V];
+            wm_walk::walk_load<V, VEC>(vol + off[u], st, d_mid, d_end, a, c, m);
+            ok[u] = c0 + u * 64 + lane < rows;
 #pragma unroll
-                for (int u = 0; u < LM_WALK_UR; ++u) {
-                    wm_walk::walk_load<V, VEC>(vol + off[u], st, d_mid, d_end, a[u], c[u], m[u]);
-                    ok[u] = c0 + u * 64 + lane < rows;
-                }
+            for (int v = 0; v < V; ++v) {
+                x[u][v] = a[v];
+                x[u][V + v] = c[v];
+                y[u * P + v] = m[v];
             }
+        }
 #pragma unroll
-            for (int u = 0; u < LM_WALK_UR; ++u) {
-                float x[F];
+        for (int u = 0; u < LM_WALK_UR; ++u) {
+            lm_small_predict<F, P>(x[u], beta, pred + u * P);
+            // a row past the end scores prediction 0 against target 0: nothing in any of the sums
 #pragma unroll
-                for (int v = 0; v < V; ++v) {
-                    x[v] = a[u][v];
-                    x[V + v] = c[u][v];
-                }
-                lm_small_predict<F, P>(x, beta, pred + u * P);
-                // a row past the end scores prediction 0 against target 0: nothing in any of the sums
-#pragma unroll
-                for (int v = 0; v < P; ++v) {
-                    pred[u * P + v] = ok[u] ? pred[u * P + v] : 0.f;
-                    y[u * P + v] = ok[u] ? m[u][v] : 0.f;
-                }
-            }
-        } else {
-            // V = 4 keeps the first form (general addressing, rows assembled while loading): the dense
-            // form above compiles to 130 VGPRs and 0.70 ms per 6.8e7 rows where this one takes 0.50
-            float x[LM_WALK_UR][F];
-            long long off[LM_WALK_UR];
-            wm_walk::walk_chunk_rows<LM_WALK_UR>(wc, c0, lane, rows, files, Z, Y, X, dmax, w, st, dv, off);
-#pragma unroll
-            for (int u = 0; u < LM_WALK_UR; ++u) {
-                float a[V], c[V], m[V];
-                wm_walk::walk_load<V, VEC>(vol + off[u], st, d_mid, d_end, a, c, m);
-                ok[u] = c0 + u * 64 + lane < rows;
-#pragma unroll
-                for (int v = 0; v < V; ++v) {
-                    x[u][v] = a[v];
-                    x[u][V + v] = c[v];
-                    y[u * P + v] = m[v];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < LM_WALK_UR; ++u) {
-                lm_small_predict<F, P>(x[u], beta, pred + u * P);
-#pragma unroll
-                for (int v = 0; v < P; ++v) {
-                    pred[u * P + v] = ok[u] ? pred[u * P + v] : 0.f;
-                    y[u * P + v] = ok[u] ? y[u * P + v] : 0.f;
-                }
+            for (int v = 0; v < P; ++v) {
+                pred[u * P + v] = ok[u] ? pred[u * P + v] : 0.f;
+                y[u * P + v] = ok[u] ? y[u * P + v] : 0.f;
             }
         }
         lm_resid_groups<0, LM_WALK_UR * P, MSLE>(pred, y, eps, sse, sae, sle);
