@@ -242,6 +242,18 @@ def test_device_rows_bit_exact_vs_host_generator():
         assert dev.get_state() == host.get_state()
         assert tuple(dev.get_state()[1]) == tuple(ostate[1]) and dev.get_state()[0] == ostate[0]
         assert host.region_index[0] >= 9 and host.region_index[1] >= 1
+        if cube == 1:
+            # the same walk through device_walk (no rows built): the Gram of the oracle's rows
+            dw = mk()
+            assert dw.device_walk_ready("cuda", 2 * len(tested), len(tested))
+            acc = torch.zeros((3 * len(tested) + 1,) * 2, device="cuda", dtype=torch.float64)
+            for k in (5, length + 1, count - length - 6):
+                ops_args = dw.device_walk(k)
+                from weather_model_amd import ops
+                ops.gram_walk(*ops_args, acc=acc)
+            assert dw.get_state() == host.get_state()
+            Zo = np.concatenate([Xo, np.ones((len(Xo), 1)), oy], axis=1).astype(np.float64)
+            np.testing.assert_allclose(acc.cpu().numpy(), Zo.T @ Zo, rtol=2e-6)
         # a generator state beyond 2^31 batches: the kernel's 64-bit walk (the run above took
         # the 31-bit fast path)
         far = (2 ** 31 + 7, ((2 ** 31 + 7) // length, 2 ** 31 + 1, 5))
