@@ -106,6 +106,14 @@ def test_multiple_regression_fit_matches_lstsq():
     m2.set_weights(w)
     np.testing.assert_allclose(m2.predict([x1[:5], x2[:5]]), pred, atol=1e-6)
 
+    # evaluate() over a device generator: the same rows as the last epoch -> the last epoch's numbers
+    gen_e = mr.WeatherDataGenerator(n_files, input_shape, length, data_dim, it, all_data, start, stats)
+    gen_e._advance_by((E - 1) * steps)
+    ev = model.evaluate(gen_e, steps=steps)
+    assert ev[0] == pytest.approx(hist.history["loss"][-1], rel=1e-9)
+    assert ev[1] == pytest.approx(hist.history["mae"][-1], rel=1e-9)
+    assert ev[2] == pytest.approx(hist.history["msle"][-1], rel=1e-9)
+
     # the fit above never built a row (CUBE_SIZE 1: Gram and metrics read the resident volume); the
     # same fit over gathered rows (WM_FIT_WALK=0) gives the same history and the same map
     assert hist.params["rows_from"].startswith("volume")

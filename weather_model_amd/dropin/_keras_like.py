@@ -489,6 +489,15 @@ class LinearStackModel:
         """[loss, *metrics] of the current map over a data source (model.py:88 style)."""
         self._need_beta()
         source = (x[0], x[1], y) if y is not None else x
+        if self.device.type == "cuda" and hasattr(source, "device_rows") and \
+                getattr(source, "device_ready", lambda: False)():
+            # a generator over a resident volume: the same device passes fit's validation uses
+            sums = self._new_sums()
+            self._stream(source, steps, None, lambda X, Y: self._sums_of(X, Y, sums), 0,
+                         on_walk=lambda *a: self._sums_of_walk(*a, sums))
+            logs = self._finish_sums(sums)
+            out = [logs[k] for k in ["loss"] + self._metric_keys]
+            return out if len(out) > 1 else out[0]
         store = _RowStore(self.F, self.P, self.device, 1 << 16)
         for batch in _batches(source, steps):
             store.add(*_as_rows(*batch))
