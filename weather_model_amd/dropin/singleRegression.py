@@ -37,6 +37,10 @@ SAVE_MODEL = False
 KERAS_MODELS_PATH = 'D:/Documents/Code/research/keras-models'
 NORMALIZE_DATA = True
 CUBE_SIZE = 6
+# Not in the reference: read every training file ONCE into a resident volume and build the batches on
+# the GPU (WeatherGenerator.preload; bit for bit the host generator's batches) instead of opening
+# three NetCDF files per sample and step.  False keeps the reference's file access pattern.
+PRELOAD_ON_DEVICE = True
 
 xr = None     # the xarray module, imported on first use (tests assign a stand-in)
 _lazy: dict = {}
@@ -350,6 +354,10 @@ def fitModelWithGenerator():
     dataset = WeatherGenerator(XTRAIN_DATA_PATH, YTRAIN_DATA_PATH, DATA_VAR, BATCH_SIZE, EPOCHS,
                                VALIDATION_SPLIT, dim, dsDim, dataRange)
     model = createCompiledModel(dim[1:])
+    if PRELOAD_ON_DEVICE:
+        import torch
+        if torch.cuda.is_available():
+            dataset.preload("cuda")
     callback = EarlyStopping(monitor='loss', patience=2)
     history = model.fit(dataset, batch_size=BATCH_SIZE, steps_per_epoch=steps, epochs=EPOCHS,
                         callbacks=[callback], verbose=1)
