@@ -252,18 +252,23 @@ class WeatherDataGenerator:
             want = torch.device("cuda", torch.cuda.current_device())   # compare like with like
         if vol is None or vol.device != want:
             tested = [d for d in DATA_VARS if VARIABLE_TEST[self.iteration][d]]
-            host = np.stack([np.stack([np.asarray(f[d][0], dtype=np.float32) for d in tested])
-                             for f in self.all_data])
+            # file by file: the host never holds a second copy of all_data
+            rowmajor = None
+            for k, f in enumerate(self.all_data):
+                one = np.stack([np.asarray(f[d][0], dtype=np.float32) for d in tested])
+                if rowmajor is None:
+                    rowmajor = torch.empty((len(self.all_data),) + one.shape, device=want)
+                rowmajor[k].copy_(torch.from_numpy(np.ascontiguousarray(one)))
             if CUBE_SIZE[self.iteration] == 1:
                 # cube 1: a row takes ONE value per (file, variable) plane.  Stored point-major,
                 # (Z, Y, X, files, vars), the rows of a batch (consecutive files at one grid point)
                 # are one contiguous read; the kernel sees the same logical axes through strides
                 # (the transposition runs on the device: numpy's strided copy of the same array
                 # takes seconds per GB on the host)
-                stored = torch.from_numpy(host).to(want).permute(2, 3, 4, 0, 1).contiguous()
+                stored = rowmajor.permute(2, 3, 4, 0, 1).contiguous()
                 vol = stored.permute(3, 4, 0, 1, 2)
             else:
-                vol = torch.from_numpy(np.ascontiguousarray(host)).to(want)
+                vol = rowmajor
             self._vol = vol
         return vol
 

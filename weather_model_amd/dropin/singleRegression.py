@@ -263,12 +263,15 @@ class WeatherGenerator:
     def preload(self, device="cuda"):
         """Read files startIndex .. dim[0]-1 once (scaled by ``normalizeData``) onto ``device``."""
         import torch
-        fields = []
-        for i in range(self.startIndex, self.dim[0]):
+        vol = None
+        for k, i in enumerate(range(self.startIndex, self.dim[0])):
             ds = _xr().open_dataset(getFilePath(i, self.dim))
-            fields.append(np.asarray(self.normalizeData(ds[self.dataVar][0]), dtype=np.float32))
+            field = np.ascontiguousarray(self.normalizeData(ds[self.dataVar][0]), dtype=np.float32)
             ds.close()
-        self._vol = torch.from_numpy(np.ascontiguousarray(np.stack(fields)[:, None])).to(device)
+            if vol is None:                 # file by file: the host never holds more than one field
+                vol = torch.empty((self.dim[0] - self.startIndex, 1) + field.shape, device=device)
+            vol[k, 0].copy_(torch.from_numpy(field))
+        self._vol = vol
         return self
 
     def rows_per_batch(self):
